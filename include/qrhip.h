@@ -1,0 +1,162 @@
+/*
+ * qrhip.h - C ABI of the MI355X (gfx950) rendering backend for QuadRay.
+ *
+ * Drop-in boundary.  The reference selects a rendering backend in
+ * rt_Platform::render0 (core/tracer/tracer.cpp:5992-6104) by switching on
+ * s_mode and calling `simd_<W>v<V>::render0(rt_SIMD_INFOX *s_inf)`
+ * (declared tracer.cpp:5882-5985, defined by each tracer_<W>v<V>.cpp through
+ * `#include "tracer.cpp"`, e.g. tracer_128v4.cpp:50-53, body tracer.cpp:1081).
+ * `qr_render0` below is what such a namespace symbol forwards to; the ~20 line
+ * forwarding TU is shown in INTEGRATION.md (and built by oracle/Makefile as
+ * oracle/ref_shim.cpp for the in-container link test).
+ *
+ * All entry points are plain C: pointers, sizes, ints.  No torch / HIP types.
+ * Return value: 0 on success, negative qr_status on failure;
+ * qr_last_error() gives a thread-local human readable message.
+ */
+#ifndef QRHIP_H
+#define QRHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qr_status
+{
+    QR_OK            =  0,
+    QR_ERR_ARG       = -1,  /* bad argument / malformed snapshot            */
+    QR_ERR_ABI       = -2,  /* unsupported reference build configuration    */
+    QR_ERR_UNSUP     = -3,  /* feature outside the hot path (path tracer)   */
+    QR_ERR_DEVICE    = -4,  /* no usable HIP device / HIP runtime error     */
+    QR_ERR_IO        = -5,
+    QR_ERR_NOMEM     = -6
+} qr_status;
+
+/*
+ * Build parameters of the reference binary that produced `s_inf`.
+ * They fix every structure offset in tracer.h (DP(Q*0x..), P, E macros).
+ *   quads         RT_SIMD_QUADS / Q   (rtbase.h:275-277; 8 in the stock x64 build)
+ *   pointer_bits  RT_POINTER          (32/64)
+ *   address_bits  RT_ADDRESS          (32/64)
+ *   element_bits  RT_ELEMENT          (32 only; fp64 builds are rejected)
+ *   endian        RT_ENDIAN           (0 little)
+ */
+typedef struct qr_abi_desc
+{
+    uint32_t struct_size;   /* = sizeof(qr_abi_desc) */
+    uint32_t quads;
+    uint32_t pointer_bits;
+    uint32_t address_bits;
+    uint32_t element_bits;
+    uint32_t endian;
+    uint32_t reserved[2];
+} qr_abi_desc;
+
+/* ------------------------------------------------------------------------ */
+/* 1. The reference entry point                                              */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * Replacement for `simd_<W>v<V>::render0(rt_SIMD_INFOX*)`, tracer.cpp:1081.
+ * Reads the structure graph under s_inf (read-only), renders rows
+ * index, index+thnum, ... of the frame on the current HIP device and writes
+ * 0x00RRGGBB pixels to s_inf->frame (host memory, stride frm_row).
+ * Re-entrant; retains no pointer after returning.
+ */
+int qr_render0(const void *s_inf, const qr_abi_desc *abi);
+
+/*
+ * Same walk as qr_render0 but, instead of rendering, serialises the flattened
+ * scene (include/qr_scene.h) to `path`.  Needs no GPU.  This is how snapshots
+ * travel from a machine that has the reference engine to one that does not.
+ */
+int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, const char *path);
+
+/* As above into a malloc'ed buffer the caller releases with qr_free. */
+int qr_flatten(const void *s_inf, const qr_abi_desc *abi, void **blob, uint64_t *size);
+void qr_free(void *blob);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Snapshot-driven rendering (what tests/bench use on the GPU box)        */
+/* ------------------------------------------------------------------------ */
+
+typedef struct qr_device_scene qr_device_scene; /* opaque, device resident */
+
+typedef struct qr_scene_info
+{
+    int32_t frm_w, frm_h, fsaa, depth;
+    int32_t n_srf, n_mat, n_lgt, n_elm, n_tiles, n_texels;
+    int32_t tile_w, tile_h;
+    uint64_t device_bytes;      /* bytes resident in HBM for this scene */
+} qr_scene_info;
+
+/* per-kind ray counters (the reference has none; see DESIGN.md "rays") */
+typedef struct qr_ray_counts
+{
+    uint64_t primary;
+    uint64_t shadow;
+    uint64_t reflect;
+    uint64_t refract;
+} qr_ray_counts;
+
+/* Upload a snapshot blob to `device` (HIP ordinal). */
+int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene **out);
+int qr_scene_destroy(qr_device_scene *scn);
+int qr_scene_get_info(const qr_device_scene *scn, qr_scene_info *info);
+
+/* Override recursion depth (s_inf->depth, tracer.h:173) of an uploaded scene. */
+int qr_scene_set_depth(qr_device_scene *scn, int depth);
+
+/*
+ * Restrict rendering to framebuffer rows [row_begin, row_end) and, inside that,
+ * to rows with (y % thnum) == index  -- the reference's thread interleave
+ * (tracer.cpp:1144-1145, 5385-5386).  Default: whole frame, index 0, thnum 1.
+ * Multi-GPU sharding uses tile-row groups through this call.
+ */
+int qr_scene_set_rows(qr_device_scene *scn, int row_begin, int row_end, int index, int thnum);
+
+/*
+ * Launch the render on `stream` (a hipStream_t passed as void*, NULL = the
+ * default stream).  `frame_dev` is DEVICE memory, frm_w*frm_h uint32, compact
+ * stride frm_w; rows outside the selected set are left untouched.  Asynchronous.
+ */
+int qr_render_async(qr_device_scene *scn, void *frame_dev, void *stream);
+
+/*
+ * Same, plus per-kind ray counting (slower kernel variant; counts are
+ * deterministic for a given scene/depth/rows).  Synchronises the stream.
+ */
+int qr_render_count(qr_device_scene *scn, void *frame_dev, void *stream, qr_ray_counts *counts);
+
+/*
+ * Convenience: render to a HOST frame buffer (stride `row_pixels`, may be
+ * negative like the reference's x_row), synchronous.
+ */
+int qr_render_host(qr_device_scene *scn, uint32_t *frame_host, int row_pixels);
+
+/*
+ * Time `iters` back-to-back launches with HIP events recorded on `stream`
+ * around each launch; returns average/min kernel milliseconds.
+ */
+int qr_render_timed(qr_device_scene *scn, void *frame_dev, void *stream,
+                    int iters, float *avg_ms, float *min_ms);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Misc                                                                   */
+/* ------------------------------------------------------------------------ */
+
+const char *qr_last_error(void);
+const char *qr_version(void);
+int qr_device_count(void);
+
+/* name of the dominant kernel as it appears in rocprofv3 --kernel-trace */
+const char *qr_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* QRHIP_H */

@@ -1,0 +1,350 @@
+/*
+ * ref_driver.cpp - TEST INFRASTRUCTURE (oracle side), not product code.
+ *
+ * Headless driver for the UNMODIFIED reference engine, compiled by
+ * oracle/Makefile against the sources where they lie under /root/reference
+ * (nothing of the reference is copied into this repository).  It uses the
+ * reference's public API only -- rt_Platform / rt_Scene::render / get_frame
+ * (core/engine/engine.h:131-136, 283-330), the way test/core_test.cpp:184,
+ * 939-1055 does -- plus one private runtime field, rt_Scene::depth
+ * (engine.h:268, copied to s_inf->depth in engine.cpp:3608), to realise the
+ * BASELINE.json configs that name a recursion depth (limit 1).
+ *
+ * What it produces:
+ *   --out F.raw      the reference's frame, frm_w*frm_h little-endian uint32
+ *   (stdout)         "hash <fnv1a64>" of the frame (pixel & 0xFFFFFF, row-major)
+ *   --snapshot F.qrs the flattened scene (include/qr_scene.h) captured through
+ *                    the drop-in shim (oracle/ref_shim.cpp -> qr_capture_snapshot);
+ *                    only in the binary linked with the shim (qr_ref_shim)
+ *   --bench N        wall-clock of N rt_Scene::render() calls (CPU baseline,
+ *                    bench.py's cpu_baseline.kind == "reference")
+ */
+#define private public          /* rt_Scene::depth only, see header comment */
+#define protected public
+#include "engine.h"
+#undef private
+#undef protected
+
+#include "all_scn.h"
+
+#include "scn_test01.h"
+#include "scn_test02.h"
+#include "scn_test03.h"
+#include "scn_test04.h"
+#include "scn_test05.h"
+#include "scn_test06.h"
+#include "scn_test07.h"
+#include "scn_test08.h"
+#include "scn_test09.h"
+#include "scn_test10.h"
+#include "scn_test11.h"
+#include "scn_test12.h"
+#include "scn_test13.h"
+#include "scn_test14.h"
+#include "scn_test15.h"
+#include "scn_test16.h"
+#include "scn_test17.h"
+#include "scn_test18.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <sys/mman.h>
+#include <sys/time.h>
+#include <pthread.h>
+#include <vector>
+#include <algorithm>
+
+/* set by the shim-linked binary: where the next shim call writes its snapshot */
+extern "C" { const char *qr_shim_snapshot_path = NULL; int qr_shim_calls = 0; int qr_shim_status = 0; }
+
+static double now_ms()
+{
+    timeval tm;
+    gettimeofday(&tm, NULL);
+    return tm.tv_sec * 1000.0 + tm.tv_usec / 1000.0;
+}
+
+static rt_pntr sys_alloc(rt_size size)
+{
+    rt_pntr ptr = mmap(NULL, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (ptr == MAP_FAILED || ptr == RT_NULL)
+    {
+        throw rt_Exception("alloc failed in ref_driver sys_alloc");
+    }
+    return ptr;
+}
+
+static rt_void sys_free(rt_pntr ptr, rt_size size)
+{
+    munmap(ptr, size);
+}
+
+/* ------------------------------------------------------------------------ */
+/* optional thread pool: same contract as root/RooT_linux.cpp:546-793       */
+/* (f_init/f_term/f_update/f_render hooks, engine.h:71-74), own design      */
+/* ------------------------------------------------------------------------ */
+
+struct Pool
+{
+    rt_Platform *pfm;
+    int thnum;
+    std::vector<pthread_t> th;
+    pthread_barrier_t go, done;
+    volatile int cmd;       /* 0 exit, 1 update, 2 render */
+    volatile int phase;
+};
+
+struct PoolArg { Pool *pool; int index; };
+
+static void *pool_worker(void *p)
+{
+    PoolArg *pa = (PoolArg *)p;
+    Pool *pool = pa->pool;
+    int index = pa->index;
+    for (;;)
+    {
+        pthread_barrier_wait(&pool->go);
+        int cmd = pool->cmd, phase = pool->phase;
+        if (cmd == 0) break;
+        rt_Scene *scn = pool->pfm->get_cur_scene();
+        try
+        {
+            if (cmd == 1) scn->update_slice(index, phase);
+            if (cmd == 2) scn->render_slice(index, phase);
+        }
+        catch (rt_Exception e)
+        {
+            fprintf(stderr, "worker %d exception: %s\n", index, e.err);
+        }
+        pthread_barrier_wait(&pool->done);
+    }
+    delete pa;
+    return NULL;
+}
+
+static int g_threads = 1;
+
+static rt_pntr pool_init(rt_si32 thnum, rt_Platform *pfm)
+{
+    Pool *pool = new Pool;
+    pool->pfm = pfm;
+    pool->thnum = g_threads;
+    pfm->set_thnum(g_threads);
+    pthread_barrier_init(&pool->go, NULL, g_threads + 1);
+    pthread_barrier_init(&pool->done, NULL, g_threads + 1);
+    pool->th.resize(g_threads);
+    for (int i = 0; i < g_threads; i++)
+    {
+        PoolArg *pa = new PoolArg; pa->pool = pool; pa->index = i;
+        pthread_create(&pool->th[i], NULL, pool_worker, pa);
+    }
+    return pool;
+}
+
+static rt_void pool_term(rt_pntr tdata, rt_si32 thnum)
+{
+    Pool *pool = (Pool *)tdata;
+    pool->cmd = 0;
+    pthread_barrier_wait(&pool->go);
+    for (size_t i = 0; i < pool->th.size(); i++) pthread_join(pool->th[i], NULL);
+    delete pool;
+}
+
+static rt_void pool_update(rt_pntr tdata, rt_si32 thnum, rt_si32 phase)
+{
+    Pool *pool = (Pool *)tdata;
+    pool->cmd = 1; pool->phase = phase;
+    pthread_barrier_wait(&pool->go);
+    pthread_barrier_wait(&pool->done);
+}
+
+static rt_void pool_render(rt_pntr tdata, rt_si32 thnum, rt_si32 phase)
+{
+    Pool *pool = (Pool *)tdata;
+    pool->cmd = 2; pool->phase = phase;
+    pthread_barrier_wait(&pool->go);
+    pthread_barrier_wait(&pool->done);
+}
+
+/* ------------------------------------------------------------------------ */
+
+static rt_SCENE *find_scene(const char *name)
+{
+    if (!strcmp(name, "demo01")) return &scn_demo01::sc_root;
+    if (!strcmp(name, "demo02")) return &scn_demo02::sc_root;
+    if (!strcmp(name, "demo03")) return &scn_demo03::sc_root;
+    if (!strcmp(name, "test01")) return &scn_test01::sc_root;
+    if (!strcmp(name, "test02")) return &scn_test02::sc_root;
+    if (!strcmp(name, "test03")) return &scn_test03::sc_root;
+    if (!strcmp(name, "test04")) return &scn_test04::sc_root;
+    if (!strcmp(name, "test05")) return &scn_test05::sc_root;
+    if (!strcmp(name, "test06")) return &scn_test06::sc_root;
+    if (!strcmp(name, "test07")) return &scn_test07::sc_root;
+    if (!strcmp(name, "test08")) return &scn_test08::sc_root;
+    if (!strcmp(name, "test09")) return &scn_test09::sc_root;
+    if (!strcmp(name, "test10")) return &scn_test10::sc_root;
+    if (!strcmp(name, "test11")) return &scn_test11::sc_root;
+    if (!strcmp(name, "test12")) return &scn_test12::sc_root;
+    if (!strcmp(name, "test13")) return &scn_test13::sc_root;
+    if (!strcmp(name, "test14")) return &scn_test14::sc_root;
+    if (!strcmp(name, "test15")) return &scn_test15::sc_root;
+    if (!strcmp(name, "test16")) return &scn_test16::sc_root;
+    if (!strcmp(name, "test17")) return &scn_test17::sc_root;
+    if (!strcmp(name, "test18")) return &scn_test18::sc_root;
+    return NULL;
+}
+
+static uint64_t fnv1a64_frame(const rt_ui32 *frame, int w, int h, int row)
+{
+    uint64_t hsh = 0xcbf29ce484222325ull;
+    for (int y = 0; y < h; y++)
+    {
+        const rt_ui32 *p = frame + (ptrdiff_t)y * row;
+        for (int x = 0; x < w; x++)
+        {
+            uint32_t v = p[x] & 0x00FFFFFF;
+            for (int b = 0; b < 4; b++)
+            {
+                hsh ^= (v >> (8 * b)) & 0xFF;
+                hsh *= 0x100000001b3ull;
+            }
+        }
+    }
+    return hsh;
+}
+
+static void usage()
+{
+    fprintf(stderr,
+        "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
+        "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
+        "              [--out F.raw] [--snapshot F.qrs] [--bench N] [--camera K]\n");
+}
+
+int main(int argc, char **argv)
+{
+    const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL;
+    int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0;
+    int n_simd = 0, k_size = 0, s_type = 0;
+    long time_ms = 0;
+
+    for (int i = 1; i < argc; i++)
+    {
+        if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_name = argv[++i];
+        else if (!strcmp(argv[i], "-w") && i + 1 < argc) w = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-h") && i + 1 < argc) h = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-t") && i + 1 < argc) time_ms = atol(argv[++i]);
+        else if (!strcmp(argv[i], "--fsaa") && i + 1 < argc) fsaa = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gamma")) gamma = 1;
+        else if (!strcmp(argv[i], "--fresnel")) fresnel = 1;
+        else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--simd") && i + 1 < argc) sscanf(argv[++i], "%d,%d,%d", &n_simd, &k_size, &s_type);
+        else if (!strcmp(argv[i], "--opts") && i + 1 < argc) opts_mode = argv[++i];
+        else if (!strcmp(argv[i], "--threads") && i + 1 < argc) g_threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
+        else if (!strcmp(argv[i], "--snapshot") && i + 1 < argc) snap_path = argv[++i];
+        else if (!strcmp(argv[i], "--bench") && i + 1 < argc) bench = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
+        else { usage(); return 2; }
+    }
+    if (scene_name == NULL) { usage(); return 2; }
+    rt_SCENE *scn = find_scene(scene_name);
+    if (scn == NULL) { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
+    if (g_threads < 1) g_threads = 1;
+
+    int rc = 0;
+    try
+    {
+        rt_Platform *pfm = g_threads > 1
+            ? new rt_Platform(sys_alloc, sys_free, g_threads, pool_init, pool_term, pool_update, pool_render)
+            : new rt_Platform(sys_alloc, sys_free, 1);
+
+        /* Gamma / Fresnel: scene opts DISABLE optimisations, and these two
+         * "optimisations" are the features being off (format.h:59-60, 73-75) */
+        if (gamma)   scn->opts |= RT_OPTS_GAMMA;
+        if (fresnel) scn->opts |= RT_OPTS_FRESNEL;
+
+        int simd = pfm->set_simd(simd_init(n_simd, s_type, k_size));
+        pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+
+        int x_row = (w + RT_SIMD_WIDTH - 1) & ~(RT_SIMD_WIDTH - 1);
+
+        rt_Scene *sc = new(pfm) rt_Scene(scn, w, h, x_row, RT_NULL, pfm);
+        if (opts_mode != NULL)
+        {
+            sc->set_opts(!strcmp(opts_mode, "none") ? RT_OPTS_NONE : RT_OPTS_FULL);
+        }
+        if (depth >= 0)
+        {
+            if (depth > RT_STACK_DEPTH) depth = RT_STACK_DEPTH;
+            sc->depth = depth;
+        }
+        for (int k = 0; k < camera; k++) sc->next_cam();
+
+        sc->render(time_ms);
+        rt_ui32 *frame = sc->get_frame();
+        int row = sc->get_x_row();
+
+        printf("scene %s w %d h %d row %d t %ld fsaa %d gamma %d fresnel %d depth %d simd %dx%dv%d threads %d\n",
+               scene_name, w, h, row, time_ms, fsaa, gamma, fresnel, (int)sc->depth,
+               (simd & 0xFF) * 128, (simd >> 16) & 0xFF, (simd >> 8) & 0xFF, pfm->get_thnum());
+        printf("hash %016llx\n", (unsigned long long)fnv1a64_frame(frame, w, h, row));
+
+        if (out_path != NULL)
+        {
+            FILE *f = fopen(out_path, "wb");
+            if (f == NULL) { fprintf(stderr, "cannot open %s\n", out_path); return 3; }
+            for (int y = 0; y < h; y++) fwrite(frame + (ptrdiff_t)y * row, 4, w, f);
+            fclose(f);
+        }
+
+        if (bench > 0)
+        {
+            std::vector<double> ms;
+            for (int i = 0; i < bench; i++)
+            {
+                double t0 = now_ms();
+                sc->render(time_ms);
+                ms.push_back(now_ms() - t0);
+            }
+            std::sort(ms.begin(), ms.end());
+            double sum = 0; for (double v : ms) sum += v;
+            printf("bench frames %d min_ms %.3f median_ms %.3f mean_ms %.3f\n",
+                   bench, ms[0], ms[ms.size() / 2], sum / ms.size());
+        }
+
+        if (snap_path != NULL)
+        {
+            /* select the namespace the shim occupies: simd_128v8 (n=1,k=1,s=8) */
+            int got = pfm->set_simd(simd_init(1, 8, 1));
+            if (((got >> 8) & 0xFF) != 8 || (got & 0xFF) != 1)
+            {
+                fprintf(stderr, "shim target 128x1v8 not selectable (got %x); is this qr_ref_shim?\n", got);
+                return 4;
+            }
+            pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+            qr_shim_snapshot_path = snap_path;
+            qr_shim_calls = 0;
+            sc->render(time_ms);
+            qr_shim_snapshot_path = NULL;
+            if (qr_shim_calls != pfm->get_thnum() || qr_shim_status != 0)
+            {
+                fprintf(stderr, "shim was called %d times, status %d\n", qr_shim_calls, qr_shim_status);
+                return 5;
+            }
+            printf("snapshot %s\n", snap_path);
+        }
+
+        delete sc;
+        delete pfm;
+    }
+    catch (rt_Exception e)
+    {
+        fprintf(stderr, "exception: %s\n", e.err);
+        rc = 1;
+    }
+    return rc;
+}

@@ -1,0 +1,55 @@
+/*
+ * qr_capi_host.cpp - the part of the C ABI (include/qrhip.h) that needs no GPU:
+ * error channel, version, graph flattening and snapshot capture.
+ */
+#include "qr_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local std::string g_qr_error;
+
+void qr_set_error(const std::string &msg) { g_qr_error = msg; }
+
+int qr_fail(int status, const std::string &msg)
+{
+    g_qr_error = msg;
+    return status;
+}
+
+extern "C" const char *qr_last_error(void) { return g_qr_error.c_str(); }
+
+extern "C" const char *qr_version(void) { return "qrhip 0.1 (gfx950)"; }
+
+extern "C" int qr_flatten(const void *s_inf, const qr_abi_desc *abi, void **blob, uint64_t *size)
+{
+    if (blob == nullptr || size == nullptr) return qr_fail(QR_ERR_ARG, "null output argument");
+    std::vector<uint8_t> out;
+    std::string err;
+    int rc = qr_flatten_impl(s_inf, abi, out, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    void *p = malloc(out.size());
+    if (p == nullptr) return qr_fail(QR_ERR_NOMEM, "out of memory");
+    memcpy(p, out.data(), out.size());
+    *blob = p;
+    *size = out.size();
+    return QR_OK;
+}
+
+extern "C" void qr_free(void *blob) { free(blob); }
+
+extern "C" int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, const char *path)
+{
+    if (path == nullptr) return qr_fail(QR_ERR_ARG, "null path");
+    std::vector<uint8_t> out;
+    std::string err;
+    int rc = qr_flatten_impl(s_inf, abi, out, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    FILE *f = fopen(path, "wb");
+    if (f == nullptr) return qr_fail(QR_ERR_IO, std::string("cannot open ") + path);
+    size_t n = fwrite(out.data(), 1, out.size(), f);
+    int rc2 = fclose(f);
+    if (n != out.size() || rc2 != 0) return qr_fail(QR_ERR_IO, std::string("short write to ") + path);
+    return QR_OK;
+}
