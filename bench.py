@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s of the gfx950 rendering backend on BASELINE.json's workload.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one full
+frame (demo scene 1 @1920x1080, reflections on, frozen at time 0) per GPU in the
+job.  Scene data and the frame buffers are resident in HBM when the timed region
+starts.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU (see DESIGN.md "Multi-GPU"): every step renders N frames; each frame's
+8-row tile rows are dealt to the N ranks in contiguous blocks (rotated per frame for
+balance), every rank renders its blocks of all N frames, then ONE RCCL all-to-all
+moves the blocks so that rank f ends the step holding the complete frame f.  Per-GPU
+work is constant in N (weak scaling); the exchange is overlapped with the next
+step's kernels on a second stream.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import gzip
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name -> (golden snapshot, reference-driver args for the CPU baseline, description)
+    "demo1_1080p": ("c2b_demo01_1080p", ["--scene", "demo01", "-w", "1920", "-h", "1080"],
+                    "demo scene 1 @1920x1080, reflections+refractions on (depth 10), t=0"),
+    "demo1_1080p_d0": ("c2_demo01_1080p_d0", ["--scene", "demo01", "-w", "1920", "-h", "1080", "--depth", "0"],
+                       "demo scene 1 @1920x1080, primary + hard-shadow rays only (depth 0)"),
+    "demo2_1080p_gf_d3": ("c3_demo02_1080p_gf_d3",
+                          ["--scene", "demo02", "-w", "1920", "-h", "1080", "--gamma", "--fresnel", "--depth", "3"],
+                          "demo scene 2 @1920x1080, Gamma+Fresnel, depth 3"),
+    "demo2_2160p_aa4": ("c4_demo02_2160p_aa4_gf",
+                        ["--scene", "demo02", "-w", "3840", "-h", "2160", "--gamma", "--fresnel", "--fsaa", "4"],
+                        "demo scene 2 @3840x2160, 4x FSAA, Gamma+Fresnel"),
+}
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_blob(name):
+    with open(os.path.join(ROOT, "tests", "golden", name + ".qrs.gz"), "rb") as f:
+        return gzip.decompress(f.read())
+
+
+def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
+    """Time the CPU path on this box's host cores (rank 0, N=1 only): the unmodified reference
+    (oracle/_ref/qr_ref, kind "reference") when its prebuilt binary travelled with the repo,
+    else our OpenMP restatement (kind "port")."""
+    cores = min(os.cpu_count() or 1, 16)
+    ref = os.path.join(ROOT, "oracle", "_ref", "qr_ref")
+    snap, ref_args, _ = WORKLOADS[workload]
+    if os.path.exists(ref):
+        try:
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="qrbench_")
+            os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
+            # calibrate with 3 frames, then fill the budget
+            def run(n):
+                out = subprocess.run([ref] + ref_args + ["--threads", str(cores), "--bench", str(n)],
+                                     cwd=tmp, capture_output=True, text=True, timeout=300)
+                line = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0].split()
+                return float(line[line.index("median_ms") + 1])
+            ms = run(3)
+            n = int(max(5, min(2000, frames_budget_s * 1000.0 / max(ms, 0.01))))
+            ms = run(n)
+            return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="reference",
+                        sample=f"{n} frames of the same workload through rt_Scene::render (update phases included), "
+                               f"median {ms:.3f} ms/frame, auto-selected SIMD target")
+        except Exception as e:  # fall through to the port
+            print(f"reference baseline failed: {e}", file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import qr_oracle
+    blob = load_blob(snap)
+    t0 = time.time(); qr_oracle.render(blob, threads=cores); dt = time.time() - t0
+    n = int(max(2, min(200, frames_budget_s / max(dt, 1e-3))))
+    ts = []
+    for _ in range(n):
+        t0 = time.time(); qr_oracle.render(blob, threads=cores); ts.append(time.time() - t0)
+    ts.sort()
+    ms = ts[len(ts) // 2] * 1e3
+    return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="port",
+                sample=f"{n} frames of the same workload with oracle/qr_oracle.c (scalar C + OpenMP), median {ms:.3f} ms/frame")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qr_loader import load_package
+    qr = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    snap, _, desc = WORKLOADS[args.workload]
+    blob = load_blob(snap)
+    scn = qr.Scene(blob, device=local_rank)
+    W, H = scn.width, scn.height
+    n_groups = (H + 7) // 8
+
+    # deterministic ray count of one frame (counting kernel variant, not timed)
+    _, rc = scn.render_count()
+    rays_per_frame = rc.total()
+    samples_per_frame = rc.primary
+
+    N = world
+    # block b (0..N-1) = tile rows [bounds[b], bounds[b+1])
+    bounds = [(n_groups * b) // N for b in range(N + 1)]
+    row_lo = [min(H, bounds[b] * 8) for b in range(N + 1)]
+
+    compute = torch.cuda.Stream()
+    comm = torch.cuda.Stream()
+    frames = [[scn.new_frame() for _ in range(N)] for _ in range(2)]    # double-buffered render targets
+    finals = [scn.new_frame() for _ in range(2)]                        # the frame this rank assembles
+    ev_render = [torch.cuda.Event() for _ in range(2)]
+    ev_comm = [torch.cuda.Event() for _ in range(2)]
+
+    def step(i):
+        buf = i & 1
+        with torch.cuda.stream(compute):
+            compute.wait_event(ev_comm[buf])            # the exchange that last read this buffer is done
+            for f in range(N):
+                b = (rank + f) % N                      # rotate blocks over frames for balance
+                scn.set_rows(row_lo[b], row_lo[b + 1], 0, 1)
+                scn.render(frames[buf][f], stream=compute)
+            ev_render[buf].record(compute)
+        if N > 1:
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_render[buf])
+                # rank r sends block (r+f)%N of frame f to rank f; receives block (s+rank)%N from rank s
+                send = [frames[buf][f][row_lo[(rank + f) % N]:row_lo[(rank + f) % N + 1]].reshape(-1) for f in range(N)]
+                recv = [finals[buf][row_lo[(s + rank) % N]:row_lo[(s + rank) % N + 1]].reshape(-1) for s in range(N)]
+                dist.all_to_all(recv, send)
+                ev_comm[buf].record(comm)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness gate inside the bench: the assembled frame must hash to the reference's
+    ok = True
+    if N > 1:
+        whole = scn.new_frame()
+        scn.set_rows(0, H, 0, 1)
+        scn.render(whole)
+        torch.cuda.synchronize()
+        ok = bool((whole == finals[(args.steps - 1) & 1]).all().item())
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    # dominant-kernel duration, HIP events on the launch stream (full-frame launches)
+    scn.set_rows(0, H, 0, 1)
+    avg_ms, min_ms = scn.render_timed(frames[0][0], max(20, min(args.steps, 200)), stream=compute)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        frames_done = args.steps * N
+        total_rays = rays_per_frame * frames_done
+        value = total_rays / dt / 1e6
+        bw = {0: 32, 1: 16, 2: 8}[scn.info.fsaa]
+        n_wg = ((W + bw - 1) // bw) * n_groups
+        scene_bytes = scn.info.device_bytes
+        alg_bytes = 4 * W * H + n_wg * scene_bytes      # frame write + scene read per workgroup
+        roofline = dict(bound="hbm", achieved=alg_bytes / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                        kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms,
+                        algorithmic_bytes_per_launch=alg_bytes,
+                        note="path is scalar-per-ray fp32 VALU work; HBM fraction is small by construction "
+                             "(4 B/pixel out + one scene read per workgroup), see DESIGN.md")
+        out = {
+            "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
+                       "frames_per_step": N, "rays_per_frame": rays_per_frame,
+                       "rays": rc.as_dict(), "parallelism": f"tile-row blocks x{N} + all-to-all" if N > 1 else "single GPU",
+                       "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
+                       "assembled_frame_matches": ok},
+            "roofline": roofline,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, rays_per_frame)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

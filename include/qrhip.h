@@ -119,11 +119,24 @@ int qr_scene_set_depth(qr_device_scene *scn, int depth);
 int qr_scene_set_rows(qr_device_scene *scn, int row_begin, int row_end, int index, int thnum);
 
 /*
+ * Multi-GPU sharding: render only the 8-row tile rows first, first+stride, ...
+ * (tile height RT_TILE_H = 8, engine.h:39).  Rank r of N uses (r, N).
+ */
+int qr_scene_set_tile_rows(qr_device_scene *scn, int first, int stride);
+
+/*
  * Launch the render on `stream` (a hipStream_t passed as void*, NULL = the
  * default stream).  `frame_dev` is DEVICE memory, frm_w*frm_h uint32, compact
  * stride frm_w; rows outside the selected set are left untouched.  Asynchronous.
  */
 int qr_render_async(qr_device_scene *scn, void *frame_dev, void *stream);
+
+/*
+ * As qr_render_async, additionally writing the visible primary hit of every
+ * pixel to `ids_dev` (int32 per pixel: surface_index << 1 | side, -1 = none).
+ * The reference has no such buffer; it is compared against the oracle's.
+ */
+int qr_render_ids_async(qr_device_scene *scn, void *frame_dev, void *ids_dev, void *stream);
 
 /*
  * Same, plus per-kind ray counting (slower kernel variant; counts are

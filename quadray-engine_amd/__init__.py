@@ -1,0 +1,174 @@
+"""quadray-engine_amd: Python binding of libqrhip.so (the C ABI in include/qrhip.h).
+
+The directory name is not a valid Python identifier, so import it by path
+(tests/conftest.py, bench.py and __graft_entry__.py use `load_package()` from
+the repository root helper `qr_loader.py`).
+
+PyTorch is used only for device memory, streams and torch.distributed; every
+pixel is computed by the hand-written HIP kernel behind the C ABI.  There is
+no CPU fallback: without the shared library or without a GPU these calls raise.
+"""
+import ctypes
+import gzip
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqrhip.so")
+
+# every symbol include/qrhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
+    "qr_scene_upload", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
+    "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_ids_async",
+    "qr_render_count", "qr_render_host", "qr_render_timed",
+    "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
+]
+
+
+class QrError(RuntimeError):
+    pass
+
+
+class SceneInfo(ctypes.Structure):
+    _fields_ = [("frm_w", ctypes.c_int32), ("frm_h", ctypes.c_int32), ("fsaa", ctypes.c_int32),
+                ("depth", ctypes.c_int32), ("n_srf", ctypes.c_int32), ("n_mat", ctypes.c_int32),
+                ("n_lgt", ctypes.c_int32), ("n_elm", ctypes.c_int32), ("n_tiles", ctypes.c_int32),
+                ("n_texels", ctypes.c_int32), ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32),
+                ("device_bytes", ctypes.c_uint64)]
+
+
+class RayCounts(ctypes.Structure):
+    _fields_ = [("primary", ctypes.c_uint64), ("shadow", ctypes.c_uint64),
+                ("reflect", ctypes.c_uint64), ("refract", ctypes.c_uint64)]
+
+    def total(self):
+        return self.primary + self.shadow + self.reflect + self.refract
+
+    def as_dict(self):
+        return dict(primary=self.primary, shadow=self.shadow, reflect=self.reflect, refract=self.refract)
+
+
+_lib = None
+
+
+def lib():
+    """Load libqrhip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(the gfx950 backend has no fallback path)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cu64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
+    L.qr_last_error.restype = ctypes.c_char_p
+    L.qr_version.restype = ctypes.c_char_p
+    L.qr_kernel_name.restype = ctypes.c_char_p
+    L.qr_device_count.restype = ci
+    L.qr_scene_upload.argtypes = [vp, cu64, ci, ctypes.POINTER(vp)]
+    L.qr_scene_destroy.argtypes = [vp]
+    L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
+    L.qr_scene_set_depth.argtypes = [vp, ci]
+    L.qr_scene_set_rows.argtypes = [vp, ci, ci, ci, ci]
+    L.qr_scene_set_tile_rows.argtypes = [vp, ci, ci]
+    L.qr_render_async.argtypes = [vp, vp, vp]
+    L.qr_render_ids_async.argtypes = [vp, vp, vp, vp]
+    L.qr_render_count.argtypes = [vp, vp, vp, ctypes.POINTER(RayCounts)]
+    L.qr_render_host.argtypes = [vp, vp, ci]
+    L.qr_render_timed.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise QrError(f"qrhip error {rc}: {lib().qr_last_error().decode()}")
+
+
+def read_snapshot(path):
+    """Return the raw snapshot bytes of a .qrs or .qrs.gz file."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    return gzip.decompress(raw) if path.endswith(".gz") else raw
+
+
+class Scene:
+    """A snapshot resident on one GPU (qr_device_scene)."""
+
+    def __init__(self, blob, device=0):
+        self._h = ctypes.c_void_p()
+        self._buf = ctypes.create_string_buffer(blob, len(blob))
+        _check(lib().qr_scene_upload(self._buf, len(blob), device, ctypes.byref(self._h)))
+        self.device = device
+        self.info = SceneInfo()
+        _check(lib().qr_scene_get_info(self._h, ctypes.byref(self.info)))
+
+    @property
+    def width(self):
+        return self.info.frm_w
+
+    @property
+    def height(self):
+        return self.info.frm_h
+
+    def close(self):
+        if self._h:
+            lib().qr_scene_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_depth(self, depth):
+        _check(lib().qr_scene_set_depth(self._h, depth))
+        self.info.depth = depth
+
+    def set_rows(self, row_begin, row_end, index=0, thnum=1):
+        _check(lib().qr_scene_set_rows(self._h, row_begin, row_end, index, thnum))
+
+    def set_tile_rows(self, first, stride):
+        _check(lib().qr_scene_set_tile_rows(self._h, first, stride))
+
+    def new_frame(self):
+        import torch
+        return torch.zeros((self.height, self.width), dtype=torch.int32, device=f"cuda:{self.device}")
+
+    @staticmethod
+    def _stream_ptr(stream):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def render(self, frame=None, stream=None, ids=None):
+        """Asynchronous launch on `stream` (default: torch's current stream)."""
+        if frame is None:
+            frame = self.new_frame()
+        sp = self._stream_ptr(stream)
+        if ids is None:
+            _check(lib().qr_render_async(self._h, ctypes.c_void_p(frame.data_ptr()), sp))
+        else:
+            _check(lib().qr_render_ids_async(self._h, ctypes.c_void_p(frame.data_ptr()),
+                                             ctypes.c_void_p(ids.data_ptr()), sp))
+        return frame
+
+    def render_count(self, frame=None, stream=None):
+        if frame is None:
+            frame = self.new_frame()
+        c = RayCounts()
+        _check(lib().qr_render_count(self._h, ctypes.c_void_p(frame.data_ptr()), self._stream_ptr(stream), ctypes.byref(c)))
+        return frame, c
+
+    def render_timed(self, frame, iters, stream=None):
+        avg, mn = ctypes.c_float(), ctypes.c_float()
+        _check(lib().qr_render_timed(self._h, ctypes.c_void_p(frame.data_ptr()), self._stream_ptr(stream),
+                                     iters, ctypes.byref(avg), ctypes.byref(mn)))
+        return avg.value, mn.value
+
+    def render_host(self):
+        import numpy as np
+        out = np.zeros((self.height, self.width), dtype=np.uint32)
+        _check(lib().qr_render_host(self._h, out.ctypes.data_as(ctypes.c_void_p), self.width))
+        return out

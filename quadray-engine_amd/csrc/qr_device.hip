@@ -1,9 +1,368 @@
-/* placeholder: replaced by the real backend once the oracle is pinned */
+/*
+ * qr_device.hip - GPU half of the C ABI (include/qrhip.h): scene upload,
+ * launches, timing, and qr_render0 (the reference entry point replacement,
+ * core/tracer/tracer.cpp:1081 / dispatcher 5992-6104).
+ *
+ * No CPU fallback exists: every entry point here fails with QR_ERR_DEVICE when
+ * no HIP device is usable.
+ */
 #include "qr_internal.h"
-#include <hip/hip_runtime.h>
+#include "qr_kernel.hpp"
 
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <string>
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess)                                                  \
+            return qr_fail(QR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct qr_device_scene
+{
+    int device;
+    void *d_blob;               /* one allocation holding every array      */
+    uint64_t blob_bytes;
+    DevScene sc;                /* device pointers + frame parameters       */
+    qr_header hdr;
+    unsigned long long *d_counters;
+    hipEvent_t ev0, ev1;
+};
+
+extern "C" const char *qr_kernel_name(void) { return "qr_render_kernel"; }
+
+extern "C" int qr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static size_t pad16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene **out)
+{
+    if (blob == nullptr || out == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    qr_scene_view v;
+    int rc = qr_scene_view_init(&v, blob, size);
+    if (rc != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc) + ")");
+    const qr_frame &fr = *v.frame;
+    if (fr.fsaa < 0 || fr.fsaa > 2) return qr_fail(QR_ERR_UNSUP, "unsupported fsaa");
+    if (fr.frm_w <= 0 || fr.frm_h <= 0 || fr.tile_w <= 0 || fr.tile_h <= 0) return qr_fail(QR_ERR_ARG, "bad frame parameters");
+
+    /* host-side validation of every index the kernel will follow, so that a
+     * malformed snapshot cannot turn into an out-of-bounds device access */
+    const int n_srf = (int)v.hdr->n_srf, n_mat = (int)v.hdr->n_mat, n_lgt = (int)v.hdr->n_lgt;
+    const int n_elm = (int)v.hdr->n_elm, n_tex = (int)v.hdr->n_texels;
+    auto ok_elm = [&](int i) { return i == QR_NULL || (i >= 0 && i < n_elm); };
+    auto ok_srf = [&](int i) { return i >= 0 && i < n_srf; };
+    for (int i = 0; i < n_elm; i++)
+    {
+        const qr_elem &e = v.elm[i];
+        if (!ok_elm(e.next)) return qr_fail(QR_ERR_ARG, "element next out of range");
+    }
+    for (uint32_t i = 0; i < v.hdr->n_tiles; i++)
+        if (!ok_elm(v.tiles[i])) return qr_fail(QR_ERR_ARG, "tile head out of range");
+    if (!ok_elm(fr.clist)) return qr_fail(QR_ERR_ARG, "clist out of range");
+    for (int i = 0; i < n_mat; i++)
+    {
+        const qr_material &m = v.mat[i];
+        uint64_t n = (uint64_t)(m.xmask + 1) * (m.ymask + 1);
+        if (m.tex < 0 || (uint64_t)m.tex + n > (uint64_t)n_tex) return qr_fail(QR_ERR_ARG, "texture out of range");
+        if (m.t_map[0] < 0 || m.t_map[0] > 1 || m.t_map[1] < 0 || m.t_map[1] > 1) return qr_fail(QR_ERR_ARG, "bad t_map");
+        if ((m.xmask & (m.xmask + 1)) != 0 || (m.ymask & (m.ymask + 1)) != 0) return qr_fail(QR_ERR_ARG, "texture size not a power of two");
+        if (((uint64_t)m.ymask << (m.yshft & 31)) + m.xmask >= n) return qr_fail(QR_ERR_ARG, "texture addressing exceeds texture");
+    }
+    /* classify lists: walk every list once with a step bound (cycle check) */
+    auto check_list = [&](int head, int kind) -> const char * {
+        /* kind 0 surfaces, 1 clippers, 2 lights */
+        int cnt = 0;
+        for (int e = head; e != QR_NULL; e = v.elm[e].next)
+        {
+            if (++cnt > n_elm) return "cyclic list";
+            const qr_elem &el = v.elm[e];
+            if (kind == 2)
+            {
+                if (el.simd < 0 || el.simd >= n_lgt) return "light index out of range";
+                if (!ok_elm(el.data)) return "shadow list out of range";
+            }
+            else if (kind == 0)
+            {
+                if (!ok_srf(el.simd)) return "surface index out of range";
+                if (el.data != QR_NULL && !ok_elm(el.data)) return "array last element out of range";
+            }
+            else
+            {
+                if (el.simd != QR_NULL)
+                {
+                    if (!ok_srf(el.simd)) return "clipper index out of range";
+                    if (v.srf[el.simd].srf_t[3] < 0 && !ok_elm(el.data)) return "clip trnode last out of range";
+                }
+            }
+        }
+        return nullptr;
+    };
+    for (uint32_t i = 0; i < v.hdr->n_tiles; i++)
+        if (const char *m = check_list(v.tiles[i], 0)) return qr_fail(QR_ERR_ARG, m);
+    if (const char *m = check_list(fr.clist, 0)) return qr_fail(QR_ERR_ARG, m);
+    for (int i = 0; i < n_srf; i++)
+    {
+        const qr_surface &s = v.srf[i];
+        if (s.trnode != QR_NULL && !ok_srf(s.trnode)) return qr_fail(QR_ERR_ARG, "trnode out of range");
+        if (s.has_trm != 0 && s.trnode == QR_NULL && s.srf_t[3] >= 0 && s.srf_t[3] < QR_TAG_SURFACE_MAX)
+            return qr_fail(QR_ERR_ARG, "transformed surface without trnode");
+        const bool real = s.srf_t[3] >= 0 && s.srf_t[3] < QR_TAG_SURFACE_MAX;
+        for (int k = 0; k < 3; k++)
+            if (((s.axes >> (2 * k)) & 3) > 2) return qr_fail(QR_ERR_ARG, "bad axis map");
+        if (!real) continue;
+        for (int k = 0; k < 2; k++)
+            if (s.mat[k] < 0 || s.mat[k] >= n_mat) return qr_fail(QR_ERR_ARG, "material index out of range");
+        if (!ok_elm(s.clip) || !ok_elm(s.lst[0]) || !ok_elm(s.lst[1]) || !ok_elm(s.lst[2]) || !ok_elm(s.lst[3]))
+            return qr_fail(QR_ERR_ARG, "surface list head out of range");
+        if (const char *m = check_list(s.clip, 1)) return qr_fail(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[0], 2)) return qr_fail(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[2], 2)) return qr_fail(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[1], 0)) return qr_fail(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[3], 0)) return qr_fail(QR_ERR_ARG, m);
+        for (int side = 0; side < 2; side++)
+            for (int e = s.lst[side * 2]; e != QR_NULL; e = v.elm[e].next)
+                if (const char *m = check_list(v.elm[e].data, 0)) return qr_fail(QR_ERR_ARG, m);
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    qr_device_scene *s = new qr_device_scene();
+    memset(s, 0, sizeof(*s));
+    s->device = device;
+    s->hdr = *v.hdr;
+
+    /* one device allocation; each array padded by one zero record so that
+     * masked-off lanes may read index 0 of an empty array */
+    size_t o_srf = 0;
+    size_t o_mat = pad16(o_srf + (size_t)(n_srf + 1) * sizeof(qr_surface));
+    size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
+    size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
+    size_t o_til = pad16(o_elm + (size_t)(n_elm + 1) * sizeof(qr_elem));
+    size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
+    size_t total = pad16(o_tex + (size_t)(n_tex + 1) * 4);
+
+    std::vector<uint8_t> host(total, 0);
+    memcpy(host.data() + o_srf, v.srf, (size_t)n_srf * sizeof(qr_surface));
+    memcpy(host.data() + o_mat, v.mat, (size_t)n_mat * sizeof(qr_material));
+    memcpy(host.data() + o_lgt, v.lgt, (size_t)n_lgt * sizeof(qr_light));
+    memcpy(host.data() + o_elm, v.elm, (size_t)n_elm * sizeof(qr_elem));
+    memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
+    memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
+
+    hipError_t e = hipMalloc(&s->d_blob, total);
+    if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+    e = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    hipEventCreate(&s->ev0);
+    hipEventCreate(&s->ev1);
+    s->blob_bytes = total;
+
+    uint8_t *d = (uint8_t *)s->d_blob;
+    s->sc.srf = (const qr_surface *)(d + o_srf);
+    s->sc.mat = (const qr_material *)(d + o_mat);
+    s->sc.lgt = (const qr_light *)(d + o_lgt);
+    s->sc.elm = (const qr_elem *)(d + o_elm);
+    s->sc.tiles = (const int32_t *)(d + o_til);
+    s->sc.texels = (const uint32_t *)(d + o_tex);
+    s->sc.fr = fr;
+    s->sc.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
+    s->sc.row_begin = 0; s->sc.row_end = fr.frm_h;
+    s->sc.index = fr.index; s->sc.thnum = fr.thnum > 0 ? fr.thnum : 1;
+    s->sc.group_first = 0; s->sc.group_stride = 1;
+    s->sc.n_groups = (fr.frm_h + 7) / 8;
+    *out = s;
+    return QR_OK;
+}
+
+extern "C" int qr_scene_destroy(qr_device_scene *s)
+{
+    if (s == nullptr) return QR_OK;
+    hipSetDevice(s->device);
+    hipEventDestroy(s->ev0);
+    hipEventDestroy(s->ev1);
+    hipFree(s->d_counters);
+    hipFree(s->d_blob);
+    delete s;
+    return QR_OK;
+}
+
+extern "C" int qr_scene_get_info(const qr_device_scene *s, qr_scene_info *info)
+{
+    if (s == nullptr || info == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    memset(info, 0, sizeof(*info));
+    info->frm_w = s->sc.fr.frm_w; info->frm_h = s->sc.fr.frm_h;
+    info->fsaa = s->sc.fr.fsaa; info->depth = s->sc.depth;
+    info->n_srf = (int32_t)s->hdr.n_srf; info->n_mat = (int32_t)s->hdr.n_mat; info->n_lgt = (int32_t)s->hdr.n_lgt;
+    info->n_elm = (int32_t)s->hdr.n_elm; info->n_tiles = (int32_t)s->hdr.n_tiles; info->n_texels = (int32_t)s->hdr.n_texels;
+    info->tile_w = s->sc.fr.tile_w; info->tile_h = s->sc.fr.tile_h;
+    info->device_bytes = s->blob_bytes;
+    return QR_OK;
+}
+
+extern "C" int qr_scene_set_depth(qr_device_scene *s, int depth)
+{
+    if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
+    if (depth < 0 || depth > QR_MAX_DEPTH) return qr_fail(QR_ERR_ARG, "depth must be 0..10 (RT_STACK_DEPTH)");
+    s->sc.depth = depth;
+    return QR_OK;
+}
+
+extern "C" int qr_scene_set_rows(qr_device_scene *s, int row_begin, int row_end, int index, int thnum)
+{
+    if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
+    const int h = s->sc.fr.frm_h;
+    if (row_begin < 0 || row_end > h || row_begin > row_end) return qr_fail(QR_ERR_ARG, "bad row range");
+    if (thnum <= 0 || index < 0 || index >= thnum) return qr_fail(QR_ERR_ARG, "bad index/thnum");
+    s->sc.row_begin = row_begin; s->sc.row_end = row_end;
+    s->sc.index = index; s->sc.thnum = thnum;
+    s->sc.group_first = row_begin / 8;
+    s->sc.group_stride = 1;
+    s->sc.n_groups = row_end > row_begin ? (row_end - 1) / 8 - row_begin / 8 + 1 : 0;
+    return QR_OK;
+}
+
+extern "C" int qr_scene_set_tile_rows(qr_device_scene *s, int first, int stride)
+{
+    if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
+    const int total = (s->sc.fr.frm_h + 7) / 8;
+    if (stride <= 0 || first < 0) return qr_fail(QR_ERR_ARG, "bad tile-row selection");
+    s->sc.row_begin = 0; s->sc.row_end = s->sc.fr.frm_h;
+    s->sc.group_first = first; s->sc.group_stride = stride;
+    s->sc.n_groups = first < total ? (total - first + stride - 1) / stride : 0;
+    return QR_OK;
+}
+
+template <bool COUNT>
+static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, hipStream_t st)
+{
+    const int fsaa = s->sc.fr.fsaa;
+    const int bw = fsaa == 0 ? 32 : fsaa == 1 ? 16 : 8;
+    dim3 grid((s->sc.fr.frm_w + bw - 1) / bw, s->sc.n_groups, 1);
+    if (grid.x == 0 || grid.y == 0) return hipSuccess;
+    hipLaunchKernelGGL(qr_render_kernel<COUNT>, grid, dim3(QR_BLOCK), 0, st,
+                       s->sc, (uint32_t *)frame_dev, ids_dev, s->d_counters);
+    return hipGetLastError();
+}
+
+extern "C" int qr_render_async(qr_device_scene *s, void *frame_dev, void *stream)
+{
+    if (s == nullptr || frame_dev == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch<false>(s, frame_dev, nullptr, (hipStream_t)stream));
+    return QR_OK;
+}
+
+extern "C" int qr_render_ids_async(qr_device_scene *s, void *frame_dev, void *ids_dev, void *stream)
+{
+    if (s == nullptr || frame_dev == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch<false>(s, frame_dev, (int32_t *)ids_dev, (hipStream_t)stream));
+    return QR_OK;
+}
+
+extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream, qr_ray_counts *counts)
+{
+    if (s == nullptr || frame_dev == nullptr || counts == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(launch<true>(s, frame_dev, nullptr, st));
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
+    return QR_OK;
+}
+
+extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream,
+                               int iters, float *avg_ms, float *min_ms)
+{
+    if (s == nullptr || frame_dev == nullptr || iters <= 0) return qr_fail(QR_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(s->device));
+    double sum = 0.0; float mn = 1e30f;
+    for (int i = 0; i < iters; i++)
+    {
+        HIP_TRY(hipEventRecord(s->ev0, st));
+        HIP_TRY(launch<false>(s, frame_dev, nullptr, st));
+        HIP_TRY(hipEventRecord(s->ev1, st));
+        HIP_TRY(hipEventSynchronize(s->ev1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        sum += ms; if (ms < mn) mn = ms;
+    }
+    if (avg_ms) *avg_ms = (float)(sum / iters);
+    if (min_ms) *min_ms = mn;
+    return QR_OK;
+}
+
+extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_pixels)
+{
+    if (s == nullptr || frame_host == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    const int w = s->sc.fr.frm_w, h = s->sc.fr.frm_h;
+    HIP_TRY(hipSetDevice(s->device));
+    void *d_frame = nullptr;
+    HIP_TRY(hipMalloc(&d_frame, (size_t)w * h * 4));
+    int rc = QR_OK;
+    hipError_t e = launch<false>(s, d_frame, nullptr, nullptr);
+    std::vector<uint32_t> tmp((size_t)w * h);
+    if (e == hipSuccess) e = hipMemcpy(tmp.data(), d_frame, (size_t)w * h * 4, hipMemcpyDeviceToHost);
+    hipFree(d_frame);
+    if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+    /* copy only the rows this call owns, honouring a negative stride (bottom-up
+     * frames, engine.cpp:2814-2850) */
+    for (int y = s->sc.row_begin; y < s->sc.row_end; y++)
+    {
+        if ((y / 8 - s->sc.group_first) % s->sc.group_stride != 0 || y / 8 < s->sc.group_first) continue;
+        if (s->sc.thnum > 1 && (y % s->sc.thnum) != s->sc.index) continue;
+        memcpy(frame_host + (ptrdiff_t)y * row_pixels, tmp.data() + (size_t)y * w, (size_t)w * 4);
+    }
+    return rc;
+}
+
+/*
+ * The reference entry point.  One call = flatten + upload + launch + copy back.
+ * The scene is re-flattened every call because the engine rebuilds its lists
+ * and animates objects every frame (engine.cpp:2976-3332); all of that is a few
+ * hundred KB.
+ */
 extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
 {
-    (void)s_inf; (void)abi;
-    return qr_fail(QR_ERR_DEVICE, "qr_render0: HIP backend not built yet");
+    std::vector<uint8_t> blob;
+    std::string err;
+    int rc = qr_flatten_impl(s_inf, abi, blob, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+
+    /* frame pointer and stride: inf_FRAME / inf_FRM_ROW, tracer.h:186-190 */
+    const uint8_t *inf = (const uint8_t *)s_inf;
+    const size_t ps = abi->pointer_bits / 8;
+    const size_t ib = (size_t)abi->quads * 0x100;
+    uint64_t p_frame = 0; int64_t row = 0;
+    if (ps == 8) { memcpy(&p_frame, inf + ib + 11 * ps, 8); memcpy(&row, inf + ib + 10 * ps, 8); }
+    else { uint32_t a; int32_t b; memcpy(&a, inf + ib + 11 * ps, 4); memcpy(&b, inf + ib + 10 * ps, 4); p_frame = a; row = b; }
+    if (p_frame == 0) return qr_fail(QR_ERR_ARG, "s_inf->frame is NULL");
+
+    int dev = 0;
+    if (const char *env = getenv("QR_DEVICE")) dev = atoi(env);
+    qr_device_scene *scn = nullptr;
+    rc = qr_scene_upload(blob.data(), blob.size(), dev, &scn);
+    if (rc != QR_OK) return rc;
+    rc = qr_render_host(scn, (uint32_t *)(uintptr_t)p_frame, (int)row);
+    qr_scene_destroy(scn);
+    return rc;
 }

@@ -1,0 +1,1318 @@
+/*
+ * qr_kernel.hpp - device code of the gfx950 rendering backend.
+ *
+ * What it computes: the reference's per-pixel pipeline `render0`
+ * (core/tracer/tracer.cpp:1081-5405): primary rays, object-list traversal with
+ * trnode transform caching and bounding-volume arrays, plane / quadric /
+ * two-plane solvers, depth + axis + custom (CSG) clipping, Phong lighting with
+ * hard shadows, refraction + Fresnel, reflection + metal/plain Fresnel,
+ * FSAA reduce, gamma, 0x00RRGGBB packing.
+ *
+ * How it is organised for CDNA4 (this is not the reference's structure):
+ *   - one lane = one ray (sample); a 64-lane wavefront = one 8x8 pixel block
+ *     (4x4 / 8x4 pixels under 4x / 2x FSAA), a 256-thread workgroup = one
+ *     32x8 reference tile, so the four waves share the tile's object list.
+ *   - WAVE-PACKET TRAVERSAL: lanes of a wave that walk the same list walk it
+ *     together; the element index is wave-uniform, so element and surface
+ *     records are fetched with scalar loads into SGPRs and only per-ray
+ *     quantities live in VGPRs.  Lanes with different lists (secondary rays
+ *     leaving different surfaces) are served group by group (__ballot /
+ *     readfirstlane) - the wave-level analogue of the reference's
+ *     CHECK_MASK NONE/FULL packet early-outs (rtbase.h:1209).
+ *   - DEFERRED SHADING: the reference shades every hit that passes the depth
+ *     test while it walks a list (overdraw); shading has no effect on the walk
+ *     and fully overwrites the lane's colour, so walking first (keeping the
+ *     depth-test sequence) and shading only the final hit is bit-identical and
+ *     costs one shading (and one set of shadow rays) per ray.
+ *   - recursion (context stack, tracer.h:426-665) becomes a per-lane explicit
+ *     stack of 16-dword frames evaluated in the reference's order
+ *     (refraction child, then reflection child), so colour arithmetic keeps the
+ *     reference's association.
+ *
+ * Numeric contract: IEEE fp32, no contraction (-ffp-contract=off), correctly
+ * rounded / and sqrt (hipcc default), compare predicates and integer
+ * conversions as in oracle/qr_oracle.c's header.
+ */
+#ifndef QR_KERNEL_HPP
+#define QR_KERNEL_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qr_scene.h"
+
+#define QR_BLOCK 256
+#define QR_MAX_DEPTH 10           /* RT_STACK_DEPTH, tracer.h:46 */
+
+struct DevScene
+{
+    const qr_surface  *__restrict__ srf;
+    const qr_material *__restrict__ mat;
+    const qr_light    *__restrict__ lgt;
+    const qr_elem     *__restrict__ elm;
+    const int32_t     *__restrict__ tiles;
+    const uint32_t    *__restrict__ texels;
+    qr_frame fr;
+    int32_t depth;
+    int32_t row_begin, row_end;   /* rows rendered by this launch            */
+    int32_t index, thnum;         /* reference row interleave                */
+    int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
+};
+
+typedef uint32_t u32;
+
+/* ------------------------------------------------------------------------ */
+/* lane primitives (same definitions as the oracle)                          */
+/* ------------------------------------------------------------------------ */
+
+__device__ __forceinline__ u32   f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(u32 u)   { return __uint_as_float(u); }
+
+__device__ __forceinline__ bool ceq(float a, float b) { return a == b; }
+__device__ __forceinline__ bool cne(float a, float b) { return !(a == b); }
+__device__ __forceinline__ bool clt(float a, float b) { return a < b; }
+__device__ __forceinline__ bool cle(float a, float b) { return a <= b; }
+__device__ __forceinline__ bool cgt(float a, float b) { return !(a <= b); }
+__device__ __forceinline__ bool cge(float a, float b) { return !(a < b); }
+
+__device__ __forceinline__ float fxor(float a, u32 m) { return u2f(f2u(a) ^ m); }
+__device__ __forceinline__ float fabs_bits(float a)   { return u2f(f2u(a) & 0x7FFFFFFFu); }
+__device__ __forceinline__ float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }
+
+__device__ __forceinline__ int32_t cvt_floor(float x)
+{
+    float f = __builtin_floorf(x);
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000u;
+}
+__device__ __forceinline__ int32_t cvt_near(float x)
+{
+    float f = __builtin_rintf(x);
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000u;
+}
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ float vget(const V3 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
+__device__ __forceinline__ void  vset(V3 &v, int i, float f)
+{
+    v.x = i == 0 ? f : v.x; v.y = i == 1 ? f : v.y; v.z = i == 2 ? f : v.z;
+}
+
+#define FLAG_SIDE 1
+#define FLAG_PASS_THRU 2
+
+__device__ __forceinline__ int  ax_map(u32 axes, int n) { return (int)((axes >> (2 * n)) & 3); }
+__device__ __forceinline__ u32  ax_sgn(u32 axes, int n) { return ((axes >> (8 + n)) & 1) ? 0x80000000u : 0u; }
+
+/* 3x3 transform, tracer.cpp:1447-1479 order */
+__device__ __forceinline__ V3 xform(const qr_surface *__restrict__ s, int has_trm, V3 in)
+{
+    float x4 = s->tci[0] * in.x;
+    float x5 = s->tcj[1] * in.y;
+    float x6 = s->tck[2] * in.z;
+    if (has_trm != 1)
+    {
+        x4 = x4 + s->tci[1] * in.y;
+        x4 = x4 + s->tci[2] * in.z;
+        x5 = x5 + s->tcj[0] * in.x;
+        x5 = x5 + s->tcj[2] * in.z;
+        x6 = x6 + s->tck[0] * in.x;
+        x6 = x6 + s->tck[1] * in.y;
+    }
+    V3 o; o.x = x4; o.y = x5; o.z = x6;
+    return o;
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-lane traversal state                                                  */
+/* ------------------------------------------------------------------------ */
+
+struct Ray
+{
+    V3 org, dir;            /* ctx_ORG, ctx_RAY_X..Z                          */
+    float tmin, tmax;       /* ctx_T_MIN, initial ctx_T_BUF                   */
+    int list;               /* list head element                              */
+    int osi;                /* ctx_PARAM(OBJ): originating surface or -1      */
+    int oflg;               /* ctx_PARAM(FLG) & 3: side | pass-thru           */
+    V3 ploc;                /* parent's local hit (parent ctx_NRM_I..K)       */
+};
+
+struct Hit
+{
+    float t;                /* final ctx_T_BUF                                */
+    int si;                 /* surface index or -1                            */
+    int side;
+    V3 loc;                 /* local (possibly conic-adjusted) hit, ctx_NEW   */
+};
+
+struct Walk
+{
+    V3 dxyz, dijk;          /* ctx_DFF_X..Z / I..K                            */
+    V3 rijk;                /* ctx_RAY_I..K                                   */
+    V3 hit;                 /* ctx_HIT                                        */
+    V3 nxyz, nijk;          /* ctx_NEW_X..Z / I..K                            */
+    V3 cxyz, cijk;          /* ctx_NRM_* used as clip temporaries             */
+    float tbuf;
+    int local_obj;          /* ctx_LOCAL(OBJ)                                 */
+    int resume;             /* element at which a bounding-volume skip ends   */
+    u32 dmask, amask;       /* ctx_DMASK / ctx_AMASK (as 0/~0 and sign bits)  */
+};
+
+/* ------------------------------------------------------------------------ */
+/* CC_clp, tracer.cpp:1597-2160                                              */
+/* all of `s`, `si` and the clipper list are wave-uniform                    */
+/* ------------------------------------------------------------------------ */
+
+__device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__restrict__ s,
+                                     const Ray &r, Walk &w, float t, int side, bool m)
+{
+    const int has_trm = s->has_trm;
+    const int sh = s->shift;
+    float x4, x5, x6;
+
+    m = m && cgt(w.tbuf, t);
+    m = m && clt(r.tmin, t);
+
+    x4 = r.dir.x * t; x4 = x4 + r.org.x; w.hit.x = x4;
+    x5 = r.dir.y * t; x5 = x5 + r.org.y; w.hit.y = x5;
+    x6 = r.dir.z * t; x6 = x6 + r.org.z; w.hit.z = x6;
+
+    if (has_trm != 0)
+    {
+        x4 = w.rijk.x * t; x4 = x4 + w.dijk.x; w.nijk.x = x4;
+        x5 = w.rijk.y * t; x5 = x5 + w.dijk.y; w.nijk.y = x5;
+        x6 = w.rijk.z * t; x6 = x6 + w.dijk.z; w.nijk.z = x6;
+    }
+    else
+    {
+        x4 = x4 - s->pos[0]; w.nxyz.x = x4;
+        x5 = x5 - s->pos[1]; w.nxyz.y = x5;
+        x6 = x6 - s->pos[2]; w.nxyz.z = x6;
+    }
+
+    /* conic singularity solver, 1706-1856 */
+    const int conic = s->conic;
+    if (conic != 0)
+    {
+        const u32 axes = s->axes;
+        const int mi = ax_map(axes, 0), mj = ax_map(axes, 1), mk = ax_map(axes, 2);
+        V3 nw = sh ? w.nijk : w.nxyz;
+        V3 df = sh ? w.dijk : w.dxyz;
+        float x0, x1, x2, x3;
+        x1 = vget(nw, mi); x1 = x1 * x1; x0 = x1;
+        if (conic != 2) { x2 = vget(nw, mj); x2 = x2 * x2; x0 = x0 + x2; }
+        x3 = vget(nw, mk); x3 = x3 * x3; x0 = x0 + x3;
+        bool hm = clt(x0, s->t_eps) && (w.dmask != 0);
+        if (hm)
+        {
+            const u32 sm = s->smask;
+            const float one = 1.0f;
+            float r4;
+            x2 = 0.0f;
+            x1 = u2f((f2u(vget(df, mi)) & sm) ^ f2u(one));
+            x3 = vget(*(const V3 *)s->sci, mi);
+            r4 = one;
+            if (conic != 2)
+            {
+                x2 = u2f((f2u(vget(df, mj)) & sm) ^ f2u(one));
+                x3 = x3 + vget(*(const V3 *)s->sci, mj);
+                r4 = r4 + one;
+            }
+            x3 = x3 / vget(*(const V3 *)s->sci, mk);
+            x3 = fxor(x3, sm);
+            float y6 = x3;
+            x3 = __builtin_sqrtf(x3);
+            y6 = y6 + r4;
+            r4 = rsq(y6);
+            r4 = r4 * s->t_eps;
+            x1 = x1 * r4; x2 = x2 * r4; x3 = x3 * r4;
+
+            const u32 tside = side ? sm : 0u;
+            x3 = fxor(x3, f2u(vget(df, mk)) & sm);
+            x3 = fxor(x3, (tside & w.amask) ^ w.amask);
+            const u32 u5 = (tside | w.amask) ^ w.amask;
+            x1 = fxor(x1, u5);
+            x2 = fxor(x2, u5);
+
+            vset(nw, mi, x1);
+            if (conic != 2) vset(nw, mj, x2);
+            vset(nw, mk, x3);
+            if (sh) w.nijk = nw; else w.nxyz = nw;
+            x4 = nw.x; x5 = nw.y; x6 = nw.z;
+        }
+    }
+
+    /* axis min/max, 1874-1927 */
+    const u32 mm = s->minmax_t;
+    if (mm & 0x01) m = m && cle(s->min[0], x4);
+    if (mm & 0x08) m = m && cge(s->max[0], x4);
+    if (mm & 0x02) m = m && cle(s->min[1], x5);
+    if (mm & 0x10) m = m && cge(s->max[1], x5);
+    if (mm & 0x04) m = m && cle(s->min[2], x6);
+    if (mm & 0x20) m = m && cge(s->max[2], x6);
+
+    /* custom clipping, 1931-2151 */
+    int e = s->clip;
+    if (e != QR_NULL && __any(m))
+    {
+        int redx = QR_NULL;
+        const int local_lst = s->trnode;
+        bool c_acc = false;
+        while (e != QR_NULL)
+        {
+            e = __builtin_amdgcn_readfirstlane(e);
+            const qr_elem el = sc.elm[e];
+            const int enext = el.next;
+            if (el.simd == QR_NULL)
+            {
+                if (el.data > 0) { m = !m && c_acc; }
+                else             { c_acc = m; m = (s->c_def != 0); }
+                e = enext;
+                continue;
+            }
+            const qr_surface *__restrict__ k = &sc.srf[el.simd];
+            const int ktag = k->srf_t[3];
+            const int ktrm = k->has_trm;
+            bool have_vec = false;
+            if (ktag >= 0)
+            {
+                if (redx != QR_NULL)
+                {
+                    w.cijk.x = w.cxyz.x - k->pos[0];
+                    w.cijk.y = w.cxyz.y - k->pos[1];
+                    w.cijk.z = w.cxyz.z - k->pos[2];
+                    if (e == redx) redx = QR_NULL;
+                    have_vec = true;
+                }
+            }
+            else if (el.simd == local_lst)
+            {
+                w.cxyz.x = w.nijk.x + s->pos[0];
+                w.cxyz.y = w.nijk.y + s->pos[1];
+                w.cxyz.z = w.nijk.z + s->pos[2];
+                redx = el.data;
+                e = enext;
+                continue;
+            }
+            if (!have_vec)
+            {
+                V3 d;
+                d.x = w.hit.x - k->pos[0];
+                d.y = w.hit.y - k->pos[1];
+                d.z = w.hit.z - k->pos[2];
+                w.cxyz = d;
+                if (ktrm != 0)
+                {
+                    V3 p = xform(k, ktrm, d);
+                    if (ktag < 0)
+                    {
+                        w.cxyz = p;
+                        redx = el.data;
+                        e = enext;
+                        continue;
+                    }
+                    w.cijk = p;
+                }
+            }
+            {
+                const V3 cv = k->shift ? w.cijk : w.cxyz;
+                const int ckind = k->srf_t[2];
+                float f4 = 0.0f, f5, f6, f1, f2, f3;
+                bool ok = true;
+                if (ckind == 1)
+                {
+                    const u32 kax = k->axes;
+                    f4 = fxor(vget(cv, ax_map(kax, 2)), ax_sgn(kax, 2));
+                }
+                else if (ckind == 2)
+                {
+                    f4 = cv.x; f1 = k->scj[0]; f1 = f1 + f1; f1 = f1 * f4;
+                    f4 = f4 * f4; f4 = f4 * k->sci[0]; f4 = f4 - f1;
+                    f5 = cv.y; f2 = k->scj[1]; f2 = f2 + f2; f2 = f2 * f5;
+                    f5 = f5 * f5; f5 = f5 * k->sci[1]; f5 = f5 - f2;
+                    f6 = cv.z; f3 = k->scj[2]; f3 = f3 + f3; f3 = f3 * f6;
+                    f6 = f6 * f6; f6 = f6 * k->sci[2]; f6 = f6 - f3;
+                    f4 = f4 - k->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                }
+                else if (ckind == 3)
+                {
+                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * k->sci[0];
+                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * k->sci[1];
+                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * k->sci[2];
+                    f4 = f4 - k->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                }
+                else
+                {
+                    ok = false;
+                }
+                if (ok)
+                {
+                    const bool rr = el.data < 0 ? cge(f4, 0.0f) : cle(f4, 0.0f);
+                    m = m && rr;
+                }
+            }
+            e = enext;
+        }
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------ */
+/* OO_cyc for a group of lanes that share the list `head` (wave-uniform)     */
+/* tracer.cpp:1341-1592, 3955-4054, 4062-4136, 4216-4277, 4378-4842          */
+/* ------------------------------------------------------------------------ */
+
+template <bool SHADOW>
+__device__ __noinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
+{
+    Walk w;
+    w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
+    w.hit = {0, 0, 0}; w.nxyz = {0, 0, 0}; w.nijk = {0, 0, 0};
+    w.cxyz = {0, 0, 0}; w.cijk = {0, 0, 0};
+    w.tbuf = r.tmax;
+    w.local_obj = QR_NULL;
+    w.resume = QR_NULL;
+    w.dmask = 0; w.amask = 0;
+
+    bool live = true;
+    int e = head;
+
+    while (e != QR_NULL)
+    {
+        e = __builtin_amdgcn_readfirstlane(e);
+        const qr_elem el = sc.elm[e];
+        const int si = el.simd;
+        const qr_surface *__restrict__ s = &sc.srf[si];
+        const int tag = s->srf_t[3];
+        const int has_trm = s->has_trm;
+        const int sh = s->shift;
+        const bool on = live && w.resume == QR_NULL;
+        const bool same = si == r.osi;
+
+        if (!__any(on))
+        {
+            /* every lane of the group is inside a bounding-volume skip (or
+             * done): nothing to compute for this element */
+            if (w.resume == e) w.resume = QR_NULL;
+            if (SHADOW && !__any(live)) break;
+            e = el.next;
+            continue;
+        }
+
+        if (on)
+        {
+            if (same)
+            {
+                if (sh) w.dijk = r.ploc; else w.dxyz = r.ploc;
+            }
+            if (tag >= 0 && w.local_obj != QR_NULL)
+            {
+                if (!same)
+                {
+                    w.dijk.x = w.dxyz.x - s->pos[0];
+                    w.dijk.y = w.dxyz.y - s->pos[1];
+                    w.dijk.z = w.dxyz.z - s->pos[2];
+                }
+                if (e == w.local_obj) w.local_obj = QR_NULL;
+            }
+            else
+            {
+                bool do_ray = true;
+                if (!same)
+                {
+                    V3 d;
+                    d.x = r.org.x - s->pos[0];
+                    d.y = r.org.y - s->pos[1];
+                    d.z = r.org.z - s->pos[2];
+                    w.dxyz = d;
+                    if (has_trm == 0)
+                    {
+                        do_ray = false;
+                    }
+                    else
+                    {
+                        V3 p = xform(s, has_trm, d);
+                        if (tag < 0) { w.dxyz = p; w.local_obj = el.data; }
+                        else         { w.dijk = p; }
+                    }
+                }
+                if (do_ray) w.rijk = xform(s, has_trm, r.dir);
+            }
+        }
+
+        if ((el.kind & 3) == 1)
+        {
+            /* AR_ptr 3955-4054 */
+            if (on)
+            {
+                const V3 ry = sh ? w.rijk : r.dir;
+                const V3 df = sh ? w.dijk : w.dxyz;
+                float x0, x1, x2, x3, x4, x5, x6, x7;
+                x1 = ry.x; x0 = s->sci[0] * x1; x5 = df.x; x7 = s->sci[0] * x5;
+                x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
+                x2 = ry.y; x0 = s->sci[1] * x2; x6 = df.y; x7 = s->sci[1] * x6;
+                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x2 = ry.z; x0 = s->sci[2] * x2; x6 = df.z; x7 = s->sci[2] * x6;
+                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x5 = x5 - s->sci[3];
+                x5 = x5 * x1;
+                x3 = x3 * x3;
+                x3 = x3 - x5;
+                if (!cle(0.0f, x3))
+                {
+                    w.resume = el.data;
+                    if (w.resume == w.local_obj) w.local_obj = QR_NULL;
+                }
+            }
+            e = el.next;
+            continue;
+        }
+
+        const int solver = s->srf_t[0];
+        if (solver != 0)
+        {
+            /* up to two candidate roots per lane, in the lane's own order */
+            float ct0 = 0.0f, ct1 = 0.0f;
+            int   cs0 = 0, cs1 = 0;
+            bool  cm0 = false, cm1 = false;
+            int   ncand = 1;
+
+            if (solver == 1)
+            {
+                /* PL_ptr 4062-4136 */
+                const u32 axes = s->axes;
+                const int mk = ax_map(axes, 2);
+                const u32 sg = ax_sgn(axes, 2);
+                const V3 ry = sh ? w.rijk : r.dir;
+                const V3 df = sh ? w.dijk : w.dxyz;
+                float dk = fxor(vget(df, mk), sg);
+                const float rk = fxor(vget(ry, mk), sg);
+                dk = fxor(dk, s->smask);
+                cm0 = on && !same && cne(0.0f, rk);
+                ct0 = dk / rk;
+                cs0 = clt(rk, 0.0f) ? 0 : 1;
+            }
+            else
+            {
+                float a, b, c, d;
+                const V3 ry = sh ? w.rijk : r.dir;
+                const V3 df = sh ? w.dijk : w.dxyz;
+                if (solver == 2)
+                {
+                    /* QD_ptr 4378-4447 */
+                    float x0, x1, x2, x3, x4, x5, x6, x7;
+                    x1 = ry.x; x0 = s->sci[0] * x1; x5 = df.x; x7 = s->sci[0] * x5;
+                    x7 = x7 - s->scj[0]; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s->scj[0]; x5 = x5 * x7;
+                    x2 = ry.y; x0 = s->sci[1] * x2; x6 = df.y; x7 = s->sci[1] * x6;
+                    x7 = x7 - s->scj[1]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s->scj[1]; x6 = x6 * x7;
+                    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                    x2 = ry.z; x0 = s->sci[2] * x2; x6 = df.z; x7 = s->sci[2] * x6;
+                    x7 = x7 - s->scj[2]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s->scj[2]; x6 = x6 * x7;
+                    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                    x5 = x5 - s->sci[3];
+                    x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
+                    a = x1; b = x4; c = x6; d = x3;
+                }
+                else
+                {
+                    /* TP_ptr 4216-4277 */
+                    const u32 axes = s->axes;
+                    const int mi = ax_map(axes, 0), mk = ax_map(axes, 2);
+                    float x0, x1, x2, x3, x4, x5, x6, x7;
+                    x1 = vget(ry, mi); x5 = vget(df, mi); x3 = vget(*(const V3 *)s->sci, mi);
+                    x2 = vget(ry, mk); x6 = vget(df, mk); x4 = vget(*(const V3 *)s->sci, mk);
+                    x0 = x5; x7 = x6;
+                    x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
+                    x5 = fabs_bits(x5);
+                    x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
+                    x4 = vget(*(const V3 *)s->sci, mk);
+                    x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
+                    x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
+                    a = x1; b = x3; c = x0; d = x5;
+                }
+
+                /* QD_rts 4449-4658 */
+                const u32 sm = s->smask;
+                const bool xmask = on && cle(0.0f, d);
+                b = fxor(b, sm);
+                const bool dm = xmask && clt(d, s->d_eps);
+                w.dmask = dm ? 0xFFFFFFFFu : 0u;
+
+                const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
+                const float bd = b + sd;
+                const bool m_pos = cle(0.0f, sd);
+                const bool m_neg = cgt(0.0f, sd);
+                const float t2n = u2f((m_neg ? f2u(c) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(c) : 0u));
+                float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
+                float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
+
+                w.amask = sm & f2u(a);
+                if (dm)
+                {
+                    if (ceq(t1n, 0.0f)) t1d = 1.0f;
+                    if (ceq(t2n, 0.0f)) t2d = 1.0f;
+                }
+                float t1 = t1n / t1d;
+                float t2 = t2n / t2d;
+                const bool t1msk = cne(t1d, 0.0f);
+                const bool t2msk = cne(t2d, 0.0f);
+                if (dm)
+                {
+                    float tdf = t1 - t2;
+                    tdf = fxor(tdf, w.amask);
+                    const bool f = cle(0.0f, tdf);
+                    tdf = f ? tdf : 0.0f;
+                    float eps = f ? s->t_eps : 0.0f;
+                    eps = eps * t1;
+                    eps = fabs_bits(eps);
+                    tdf = tdf * -0.5f;
+                    tdf = tdf - eps;
+                    tdf = fxor(tdf, w.amask);
+                    tdf = (t1msk && t2msk) ? tdf : 0.0f;
+                    t1 = t1 + tdf;
+                    t2 = t2 - tdf;
+                }
+
+                const bool inner_first = xmask && cgt(0.0f, a);
+                /* CHECK_SIDE 531-540 */
+                const int f3 = r.oflg & (FLAG_SIDE | FLAG_PASS_THRU);
+                const bool skip_outer = same && (f3 == 1 || f3 == 2);
+                const bool skip_inner = same && (f3 == 0 || f3 == 3);
+                const bool mo = xmask && t1msk && !skip_outer;
+                const bool mi2 = xmask && t2msk && !skip_inner;
+                ncand = 2;
+                if (inner_first) { ct0 = t2; cs0 = 1; cm0 = mi2; ct1 = t1; cs1 = 0; cm1 = mo; }
+                else             { ct0 = t1; cs0 = 0; cm0 = mo;  ct1 = t2; cs1 = 1; cm1 = mi2; }
+            }
+
+            bool done = false;
+#pragma nounroll
+            for (int p = 0; p < ncand; p++)
+            {
+                const float t = p == 0 ? ct0 : ct1;
+                const int side = p == 0 ? cs0 : cs1;
+                bool m = (p == 0 ? cm0 : cm1) && !done;
+                if (!__any(m)) continue;
+                m = clip(sc, s, r, w, t, side, m);
+                if (m)
+                {
+                    done = true;
+                    if (SHADOW)
+                    {
+                        /* CHECK_SHAD 549-589 */
+                        const int props = side ? s->props[1] : s->props[0];
+                        const bool no_shadow = (props & QR_PROP_LIGHT) ||
+                                               ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT));
+                        if (!no_shadow) { occluded = true; live = false; }
+                    }
+                    else
+                    {
+                        /* PAINT_FRAG 653-662: depth write; shading is deferred */
+                        w.tbuf = t;
+                        h.t = t; h.si = si; h.side = side;
+                        h.loc = sh ? w.nijk : w.nxyz;
+                    }
+                }
+            }
+        }
+
+        if (w.resume == e) w.resume = QR_NULL;
+        if (SHADOW && !__any(live)) break;
+        e = el.next;
+    }
+}
+
+/*
+ * Wave-wide traversal: lanes with `active` walk their lists; lanes that share
+ * a list head are walked together.
+ */
+template <bool SHADOW>
+__device__ __forceinline__ void traverse(const DevScene &sc, bool active, const Ray &r, Hit &h, bool &occluded)
+{
+    h.t = r.tmax; h.si = QR_NULL; h.side = 0; h.loc = {0, 0, 0};
+    occluded = false;
+    active = active && r.list != QR_NULL;
+    unsigned long long pending = __ballot(active);
+    while (pending != 0)
+    {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int head = __shfl(r.list, leader);
+        const bool mine = active && r.list == head;
+        pending &= ~__ballot(mine);
+        if (mine)
+        {
+            walk_list<SHADOW>(sc, __builtin_amdgcn_readfirstlane(head), r, h, occluded);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* shading of the final hit, tracer.cpp:2166-3930 without the child packets  */
+/* ------------------------------------------------------------------------ */
+
+struct Frame
+{
+    float col[3];
+    float c_trn, c_rfl, x0;
+    float rdir[3];
+    float hit[3];
+    float loc[3];
+    int   meta;             /* si << 4 | side << 3 | rf << 2 | phase (1 TR, 2 RF) */
+};
+
+struct Shaded
+{
+    V3 col;                 /* local colour after lights                      */
+    V3 hit;                 /* world hit = child origin                       */
+    V3 loc;                 /* local hit = child's ploc                       */
+    V3 tdir;                /* refraction child direction (ctx_NEW after TR)  */
+    V3 rdir;                /* reflection child direction (ctx_NEW after RF)  */
+    float c_trn, c_rfl, x0;
+    bool want_tr;           /* refraction child exists (M_TRN, not opaque)    */
+    bool want_rf;           /* reflection pass applies (RF_ini reached)       */
+    int  lst_tr, lst_rf;
+};
+
+struct Counters { u32 primary, shadow, reflect, refract; };
+
+template <bool COUNT>
+__device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r, const Hit &h,
+                                      Shaded &o, Counters &cnt)
+{
+    /* per-lane (divergent) material data; everything below is lane-private
+     * except the wave-wide shadow traversals in the light loop */
+    const int si = act ? h.si : 0;
+    const int side = h.side;
+    const qr_surface *__restrict__ s = &sc.srf[si];
+    const qr_frame &fr = sc.fr;
+
+    V3 nrm = {0, 0, 1};
+    V3 tex = {0, 0, 0};
+    V3 col = {0, 0, 0};
+    V3 hit = {0, 0, 0};
+    int props = 0;
+    int mi = 0;
+    int le = QR_NULL;
+
+    if (act)
+    {
+        const float t = h.t;
+        float x0, x1, x2, x3, x4, x5, x6;
+        x4 = r.dir.x * t; hit.x = x4 + r.org.x;
+        x5 = r.dir.y * t; hit.y = x5 + r.org.y;
+        x6 = r.dir.z * t; hit.z = x6 + r.org.z;
+
+        props = side | s->props[side];
+        mi = s->mat[side];
+        const u32 axes = s->axes;
+        const u32 tside = side ? s->smask : 0u;
+        const int has_trm = s->has_trm;
+        const int nkind = s->srf_t[1];
+        float tu = 0.0f, tv = 0.0f;
+        V3 ln = {0, 0, 0};                          /* normal in surface space */
+
+        if (nkind == 1)
+        {
+            /* PL_mat 4139-4193 */
+            if (props & QR_PROP_TEXTURE)
+            {
+                tu = fxor(vget(h.loc, ax_map(axes, 0)), ax_sgn(axes, 0));
+                tv = fxor(vget(h.loc, ax_map(axes, 1)), ax_sgn(axes, 1));
+            }
+            x6 = fxor(1.0f, tside);
+            vset(ln, ax_map(axes, 2), fxor(x6, ax_sgn(axes, 2)));
+        }
+        else
+        {
+            /* QD_mat 4845-4905 / TP_mat 4280-4336 */
+            x4 = h.loc.x * s->sci[0]; x5 = h.loc.y * s->sci[1]; x6 = h.loc.z * s->sci[2];
+            if (nkind == 2)
+            {
+                x4 = x4 - s->scj[0]; x5 = x5 - s->scj[1]; x6 = x6 - s->scj[2];
+            }
+            x1 = x4 * x4; x2 = x5 * x5; x3 = x6 * x6;
+            x1 = x1 + x2; x1 = x1 + x3;
+            x0 = rsq(x1);
+            x0 = fxor(x0, tside);
+            ln.x = x4 * x0; ln.y = x5 * x0; ln.z = x6 * x0;
+        }
+        nrm = ln;
+        if (has_trm != 0)
+        {
+            /* MT_nrm 2184-2263: transposed trnode matrix */
+            const qr_surface *__restrict__ tr = &sc.srf[s->trnode];
+            const int ttrm = tr->has_trm;
+            x1 = ln.x; x2 = ln.y; x3 = ln.z;
+            x4 = tr->tci[0] * x1;
+            x5 = tr->tcj[1] * x2;
+            x6 = tr->tck[2] * x3;
+            if (ttrm != 1)
+            {
+                x4 = x4 + tr->tcj[0] * x2;
+                x4 = x4 + tr->tck[0] * x3;
+                x5 = x5 + tr->tci[1] * x1;
+                x5 = x5 + tr->tck[1] * x3;
+                x6 = x6 + tr->tci[2] * x1;
+                x6 = x6 + tr->tcj[2] * x2;
+            }
+            if (ttrm != 2)
+            {
+                x1 = x4 * x4; x2 = x5 * x5; x3 = x6 * x6;
+                x1 = x1 + x2; x1 = x1 + x3;
+                x0 = rsq(x1);
+                x4 = x4 * x0; x5 = x5 * x0; x6 = x6 * x0;
+            }
+            nrm.x = x4; nrm.y = x5; nrm.z = x6;
+        }
+
+        /* MT_tex 2293-2327, PAINT_FRAG / PAINT_COLX 653-673 */
+        const qr_material *__restrict__ mt = &sc.mat[mi];
+        u32 toff = 0;
+        if (props & QR_PROP_TEXTURE)
+        {
+            x4 = mt->t_map[0] ? tv : tu;
+            x5 = mt->t_map[1] ? tv : tu;
+            x4 = x4 - mt->xoffs; x5 = x5 - mt->yoffs;
+            x4 = x4 * mt->xscal; x5 = x5 * mt->yscal;
+            const int32_t iu = cvt_floor(x4) & (int32_t)mt->xmask;
+            const int32_t iv = cvt_floor(x5) & (int32_t)mt->ymask;
+            toff = (u32)iu + ((u32)iv << (mt->yshft & 31));
+        }
+        const u32 texel = sc.texels[mt->tex + (int32_t)toff];
+        const u32 cmask = mt->cmask;
+        const float clampv = mt->clamp;
+        tex.x = (float)(int32_t)((texel >> 16) & cmask) / clampv;
+        tex.y = (float)(int32_t)((texel >> 8) & cmask) / clampv;
+        tex.z = (float)(int32_t)(texel & cmask) / clampv;
+        if (props & QR_PROP_GAMMA) { tex.x = tex.x * tex.x; tex.y = tex.y * tex.y; tex.z = tex.z * tex.z; }
+
+        if (props & QR_PROP_LIGHT)
+        {
+            col = tex;                              /* LT_set */
+        }
+        else
+        {
+            col.x = tex.x * fr.amb[0];
+            col.y = tex.y * fr.amb[1];
+            col.z = tex.z * fr.amb[2];
+            le = s->lst[side * 2];
+        }
+    }
+
+    /* lights, 2758-3156: wave-wide loop, per-lane light elements */
+    while (__any(le != QR_NULL))
+    {
+        const bool has = le != QR_NULL;
+        const qr_elem el = sc.elm[has ? le : 0];
+        const qr_light *__restrict__ lg = &sc.lgt[has ? el.simd : 0];
+        V3 L = {0, 0, 0};
+        float dot = 0.0f;
+        bool lm = false;
+        if (has)
+        {
+            float x1, x2, x3, x0;
+            x1 = lg->pos[0] - hit.x; L.x = x1; x1 = x1 * nrm.x;
+            x2 = lg->pos[1] - hit.y; L.y = x2; x2 = x2 * nrm.y;
+            x3 = lg->pos[2] - hit.z; L.z = x3; x3 = x3 * nrm.z;
+            x0 = x1; x0 = x0 + x2; x0 = x0 + x3;
+            dot = x0;
+            lm = clt(0.0f, x0);
+        }
+        Ray sr;
+        sr.org = hit; sr.dir = L; sr.tmin = 0.0f; sr.tmax = lg->t_max;
+        sr.list = el.data; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
+        Hit sh; bool occ;
+        if (COUNT) { if (lm) cnt.shadow++; }
+        traverse<true>(sc, lm, sr, sh, occ);
+        if (lm && !occ)
+        {
+            const qr_material *__restrict__ mt = &sc.mat[mi];
+            float x0, x1, x2, x3, x4, x5, x6, x7;
+            x1 = L.x; x4 = x1 * x1;
+            x2 = L.y; x5 = x2 * x2;
+            x3 = L.z; x6 = x3 * x3;
+            x4 = x4 + x5; x4 = x4 + x6;
+            const float r2 = x4;
+            x0 = dot;
+            if (props & QR_PROP_DIFFUSE)
+            {
+                x6 = x4;
+                x5 = rsq(x4);
+                x4 = x5 * x6;
+                x6 = x6 * lg->a_qdr;
+                x4 = x4 * lg->a_lnr;
+                x6 = x6 + lg->a_cnt;
+                x6 = x6 + x4;
+                x4 = rsq(x6);
+                x6 = x0;
+                x0 = x0 * x4;
+                x0 = x0 * x5;
+                x0 = x0 * mt->l_dff;
+            }
+            else
+            {
+                x6 = x0;
+                x0 = 0.0f;
+            }
+            bool plain = false;
+            float spec = 0.0f;
+            if (props & QR_PROP_SPECULAR)
+            {
+                x4 = x6; x5 = x6;
+                x4 = x4 * nrm.x; x1 = x1 - x4; x1 = x1 - x4;
+                x5 = x5 * nrm.y; x2 = x2 - x5; x2 = x2 - x5;
+                x6 = x6 * nrm.z; x3 = x3 - x6; x3 = x3 - x6;
+                x4 = r.dir.x; x1 = x1 * x4; x4 = x4 * x4;
+                x5 = r.dir.y; x2 = x2 * x5; x5 = x5 * x5;
+                x6 = r.dir.z; x3 = x3 * x6; x6 = x6 * x6;
+                x6 = x6 + x4; x6 = x6 + x5;
+                x1 = x1 + x2; x1 = x1 + x3;
+                if (clt(0.0f, x1))
+                {
+                    x4 = r2;
+                    x5 = rsq(x6); x1 = x1 * x5;
+                    x5 = rsq(x4); x1 = x1 * x5;
+                    /* fixed-point 28.4 power, 2981-3039 */
+                    const u32 lpow = mt->l_pow;
+                    u32 pw = lpow & 0xF;
+                    x2 = x1; x4 = x1; x1 = 1.0f;
+                    while (pw != 0)
+                    {
+                        x4 = __builtin_sqrtf(x4);
+                        const u32 bit = pw & 0x8;
+                        pw = (pw << 1) & 0xF;
+                        if (bit) x1 = x1 * x4;
+                    }
+                    pw = lpow >> 4;
+                    if (pw != 0)
+                    {
+                        x3 = x1; x1 = 1.0f;
+                        do
+                        {
+                            const u32 bit = pw & 1;
+                            pw >>= 1;
+                            if (bit) x1 = x1 * x2;
+                            x2 = x2 * x2;
+                        }
+                        while (pw != 0);
+                        x1 = x1 * x3;
+                    }
+                    x1 = x1 * mt->l_spc;
+                    if (props & QR_PROP_METAL) { x0 = x0 + x1; }
+                    else { plain = true; spec = x1; }
+                }
+            }
+            if (!plain)
+            {
+                x1 = tex.x * lg->col[0];
+                x2 = tex.y * lg->col[1];
+                x3 = tex.z * lg->col[2];
+                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+            }
+            else
+            {
+                x7 = spec;
+                x1 = tex.x; x2 = tex.y; x3 = tex.z;
+                x4 = lg->col[0]; x5 = lg->col[1]; x6 = lg->col[2];
+                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+                x1 = x1 * x4; x2 = x2 * x5; x3 = x3 * x6;
+                x4 = x4 * x7; x5 = x5 * x7; x6 = x6 * x7;
+                x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
+                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+            }
+        }
+        le = has ? el.next : QR_NULL;
+    }
+
+    o.col = col; o.hit = hit; o.loc = h.loc;
+    o.tdir = {0, 0, 0}; o.rdir = {0, 0, 0};
+    o.c_trn = 0.0f; o.c_rfl = 0.0f; o.x0 = 0.0f;
+    o.want_tr = false; o.want_rf = false;
+    o.lst_tr = QR_NULL; o.lst_rf = QR_NULL;
+
+    if (act)
+    {
+        const qr_material *__restrict__ mt = &sc.mat[mi];
+        const float m_trn_c = mt->c_trn, m_rfl_c = mt->c_rfl;
+        float c_trn = m_trn_c, c_rfl = m_rfl_c;
+        float x0 = 0.0f, x1, x2, x3, x4 = 0.0f, x5, x6 = 0.0f, x7 = 0.0f;
+        bool m_trn = true;
+
+        /* transparency 3185-3552 */
+        if (!(props & QR_PROP_OPAQUE))
+        {
+            const bool do_rfi = (props & QR_PROP_REFRACT) || (props & QR_PROP_FRESNEL);
+            bool tir = false;
+            V3 nd = r.dir;
+            if (do_rfi)
+            {
+                x1 = r.dir.x; x7 = x1 * x1; x0 = x7;
+                x2 = r.dir.y; x7 = x2 * x2; x0 = x0 + x7;
+                x3 = r.dir.z; x7 = x3 * x3; x0 = x0 + x7;
+                x7 = rsq(x0);
+                x1 = x1 * x7; x2 = x2 * x7; x3 = x3 * x7;
+                x7 = x1 * nrm.x; x0 = x7;
+                x7 = x2 * nrm.y; x0 = x0 + x7;
+                x7 = x3 * nrm.z; x0 = x0 + x7;
+                x4 = x0;
+                x6 = mt->c_rfr;
+                x0 = x0 * x6;
+                x7 = x0 * x0;
+                x7 = x7 + 1.0f;
+                x7 = x7 - mt->rfr_2;
+                if (props & QR_PROP_FRESNEL)
+                {
+                    m_trn = cle(0.0f, x7);
+                    if (!m_trn)
+                    {
+                        c_trn = 0.0f;
+                        c_rfl = m_rfl_c + m_trn_c;
+                        tir = true;
+                    }
+                }
+                if (!tir)
+                {
+                    x7 = __builtin_sqrtf(x7);
+                    x0 = x0 + x7;
+                    if (props & QR_PROP_REFRACT)
+                    {
+                        x5 = nrm.x * x0; x1 = x1 * x6; nd.x = x1 - x5;
+                        x5 = nrm.y * x0; x2 = x2 * x6; nd.y = x2 - x5;
+                        x5 = nrm.z * x0; x3 = x3 * x6; nd.z = x3 - x5;
+                    }
+                }
+            }
+            if (!tir)
+            {
+                if (props & QR_PROP_FRESNEL)
+                {
+                    x1 = x4;
+                    x2 = x1; x2 = x2 * x6; x2 = x2 - x7;
+                    x7 = x7 * x6;
+                    x3 = x1;
+                    x1 = x1 + x7;
+                    x3 = x3 - x7;
+                    x0 = x0 / x2;
+                    x1 = x1 / x3;
+                    x0 = x0 * x0; x1 = x1 * x1;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                    const float f = x0 * m_trn_c;   /* m_trn is true here */
+                    c_trn = m_trn_c - f;
+                    c_rfl = m_rfl_c + f;
+                }
+                o.want_tr = m_trn;
+                o.tdir = nd;
+                o.lst_tr = s->lst[(1 - side) * 2 + 1];
+            }
+        }
+
+        /* TR_mix factor 3564-3573 */
+        x0 = 1.0f - m_trn_c;
+        x0 = x0 - m_rfl_c;
+        x0 = cle(0.0f, x0) ? x0 : 0.0f;
+        o.x0 = x0;
+
+        /* reflections 3604-3815 */
+        if ((props & QR_PROP_REFLECT) ||
+            (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL)))
+        {
+            x1 = r.dir.x; x4 = nrm.x; x7 = x1 * x1; x0 = x7;
+            x2 = r.dir.y; x5 = nrm.y; x7 = x2 * x2; x0 = x0 + x7;
+            x3 = r.dir.z; x6 = nrm.z; x7 = x3 * x3; x0 = x0 + x7;
+            x7 = rsq(x0);
+            x1 = x1 * x7; x2 = x2 * x7; x3 = x3 * x7;
+            x7 = x1 * x4; x0 = x7;
+            x7 = x2 * x5; x0 = x0 + x7;
+            x7 = x3 * x6; x0 = x0 + x7;
+            x4 = x4 * x0; x1 = x1 - x4; x1 = x1 - x4; o.rdir.x = x1;
+            x5 = x5 * x0; x2 = x2 - x5; x2 = x2 - x5; o.rdir.y = x2;
+            x6 = x6 * x0; x3 = x3 - x6; x3 = x3 - x6; o.rdir.z = x3;
+
+            if ((props & QR_PROP_FRESNEL) && (props & QR_PROP_OPAQUE))
+            {
+                if (props & QR_PROP_METAL)
+                {
+                    x6 = mt->c_rcp;
+                    x4 = x0; x4 = x4 * x6; x4 = x4 + x4;
+                    x0 = x0 * x0;
+                    x6 = x6 * x6;
+                    x6 = x6 + mt->ext_2;
+                    x1 = x0; x1 = x1 * x6;
+                    x0 = x0 + x6;
+                    x1 = x1 + 1.0f;
+                    x2 = x0; x3 = x1;
+                    x0 = x0 + x4; x1 = x1 + x4;
+                    x2 = x2 - x4; x3 = x3 - x4;
+                    x0 = x0 / x2; x1 = x1 / x3;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                }
+                else
+                {
+                    x4 = x0;
+                    x6 = mt->c_rfr;
+                    x0 = x0 * x6;
+                    x7 = x0 * x0;
+                    x7 = x7 + 1.0f;
+                    x7 = x7 - mt->rfr_2;
+                    x7 = __builtin_sqrtf(x7);
+                    x0 = x0 + x7;
+                    x1 = x4;
+                    x2 = x1; x2 = x2 * x6; x2 = x2 - x7;
+                    x7 = x7 * x6;
+                    x3 = x1;
+                    x1 = x1 + x7;
+                    x3 = x3 - x7;
+                    x0 = x0 / x2; x1 = x1 / x3;
+                    x0 = x0 * x0; x1 = x1 * x1;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                }
+                x0 = x0 - 1.0f;
+                x0 = x0 * m_rfl_c;
+                c_rfl = m_rfl_c + x0;
+            }
+            o.want_rf = true;
+            o.lst_rf = s->lst[side * 2 + 1];
+        }
+        o.c_trn = c_trn;
+        o.c_rfl = c_rfl;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* the kernel                                                                */
+/* ------------------------------------------------------------------------ */
+
+__device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
+
+template <bool COUNT>
+__global__ __launch_bounds__(QR_BLOCK)
+void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
+                      unsigned long long *__restrict__ counters)
+{
+    const qr_frame &fr = sc.fr;
+    const int fsaa = fr.fsaa;
+    const int ns = 1 << fsaa;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6;
+    const int lane = tid & 63;
+    const int pix = lane >> fsaa;               /* pixel index inside the wave */
+    const int k = lane & (ns - 1);              /* sample index inside the pixel */
+
+    /* wave footprint: 8x8 pixels (no AA), 8x4 (2x), 4x4 (4x); block = 32x8 / 16x8 / 8x8 */
+    int bw, px, py;
+    if (fsaa == 0)      { bw = 32; px = wv * 8 + (pix & 7);        py = pix >> 3; }
+    else if (fsaa == 1) { bw = 16; px = (wv & 1) * 8 + (pix & 7);  py = (wv >> 1) * 4 + (pix >> 3); }
+    else                { bw = 8;  px = (wv & 1) * 4 + (pix & 3);  py = (wv >> 1) * 4 + (pix >> 2); }
+
+    const int group = sc.group_first + (int)blockIdx.y * sc.group_stride;
+    const int x = (int)blockIdx.x * bw + px;
+    const int y = group * 8 + py;
+
+    bool inside = x < fr.frm_w && y < fr.frm_h && y >= sc.row_begin && y < sc.row_end;
+    if (inside && sc.thnum > 1) inside = (y % sc.thnum) == sc.index;
+
+    Counters cnt = {0, 0, 0, 0};
+
+    /* primary ray, tracer.cpp:1287-1322; sample offsets engine.cpp:3480-3550 */
+    Ray ray;
+    {
+        int ai = 0;
+        if (fsaa == 1) ai = (x & 1) * 2 + k;
+        if (fsaa == 2) ai = k;
+        float hs = (float)x + fr.hor_a[ai]; hs = hs + 0.0f;
+        float vs = (float)y + fr.ver_a[ai]; vs = vs + 0.0f;
+        float x1 = fr.hor[0] * hs, x2 = fr.hor[1] * hs, x3 = fr.hor[2] * hs;
+        float x4 = fr.ver[0] * vs, x5 = fr.ver[1] * vs, x6 = fr.ver[2] * vs;
+        x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
+        ray.dir.x = x1 + fr.dir[0];
+        ray.dir.y = x2 + fr.dir[1];
+        ray.dir.z = x3 + fr.dir[2];
+        ray.org.x = fr.org[0]; ray.org.y = fr.org[1]; ray.org.z = fr.org[2];
+        ray.tmin = fr.t_min; ray.tmax = fr.t_max;
+        ray.osi = QR_NULL; ray.oflg = 0;
+        ray.ploc = {0, 0, 0};
+        ray.list = QR_NULL;
+        if (inside)
+        {
+            const int tile = (y / fr.tile_h) * fr.tls_row + (x / fr.tile_w);
+            ray.list = sc.tiles[tile];
+        }
+    }
+
+    Frame stk[QR_MAX_DEPTH];
+    int sp = 0;
+    int mode = inside ? 0 : 2;                  /* 0 trace, 1 return, 2 done */
+    V3 ret = {0, 0, 0};
+    int hit_id = -1;
+    const int depth = sc.depth;
+
+    if (COUNT && inside) cnt.primary++;
+
+    while (__any(mode != 2))
+    {
+        const bool tr = mode == 0;
+        if (__any(tr))
+        {
+            Hit h; bool occ;
+            traverse<false>(sc, tr, ray, h, occ);
+            const bool got = tr && h.si != QR_NULL;
+            if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
+            if (got && sp == 0) hit_id = (h.si << 1) | h.side;
+
+            Shaded o;
+            shade<COUNT>(sc, got, ray, h, o, cnt);
+
+            if (got)
+            {
+                const bool can_spawn = (depth - sp) != 0;
+                const int meta = (h.si << 4) | (h.side << 3) | (o.want_rf ? 4 : 0);
+                if (o.want_tr && can_spawn)
+                {
+                    Frame &f = stk[sp];
+                    f.col[0] = o.col.x; f.col[1] = o.col.y; f.col[2] = o.col.z;
+                    f.c_trn = o.c_trn; f.c_rfl = o.c_rfl; f.x0 = o.x0;
+                    f.rdir[0] = o.rdir.x; f.rdir[1] = o.rdir.y; f.rdir[2] = o.rdir.z;
+                    f.hit[0] = o.hit.x; f.hit[1] = o.hit.y; f.hit[2] = o.hit.z;
+                    f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
+                    f.meta = meta | 1;
+                    sp++;
+                    ray.org = o.hit; ray.dir = o.tdir; ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                    ray.list = o.lst_tr; ray.osi = h.si; ray.oflg = h.side | FLAG_PASS_THRU;
+                    ray.ploc = o.loc;
+                    mode = 0;
+                    if (COUNT) cnt.refract++;
+                }
+                else
+                {
+                    /* TR_mix with a zero child colour, 3560-3598 */
+                    V3 c;
+                    c.x = 0.0f + o.col.x * o.x0;
+                    c.y = 0.0f + o.col.y * o.x0;
+                    c.z = 0.0f + o.col.z * o.x0;
+                    if (o.want_rf && can_spawn)
+                    {
+                        Frame &f = stk[sp];
+                        f.col[0] = c.x; f.col[1] = c.y; f.col[2] = c.z;
+                        f.c_trn = o.c_trn; f.c_rfl = o.c_rfl; f.x0 = o.x0;
+                        f.rdir[0] = o.rdir.x; f.rdir[1] = o.rdir.y; f.rdir[2] = o.rdir.z;
+                        f.hit[0] = o.hit.x; f.hit[1] = o.hit.y; f.hit[2] = o.hit.z;
+                        f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
+                        f.meta = meta | 2;
+                        sp++;
+                        ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                        ray.list = o.lst_rf; ray.osi = h.si; ray.oflg = h.side;
+                        ray.ploc = o.loc;
+                        mode = 0;
+                        if (COUNT) cnt.reflect++;
+                    }
+                    else
+                    {
+                        if (o.want_rf) { c.x = 0.0f + c.x; c.y = 0.0f + c.y; c.z = 0.0f + c.z; }
+                        ret = c;
+                        mode = 1;
+                    }
+                }
+            }
+        }
+
+        if (mode == 1)
+        {
+            if (sp == 0)
+            {
+                mode = 2;
+            }
+            else
+            {
+                Frame &f = stk[sp - 1];
+                const int phase = f.meta & 3;
+                if (phase == 1)
+                {
+                    /* TR_ret + TR_mix 3534-3598 */
+                    V3 c;
+                    c.x = ret.x * f.c_trn + f.col[0] * f.x0;
+                    c.y = ret.y * f.c_trn + f.col[1] * f.x0;
+                    c.z = ret.z * f.c_trn + f.col[2] * f.x0;
+                    if (f.meta & 4)
+                    {
+                        /* reflection child of the same node (depth budget is
+                         * the same as for the refraction child) */
+                        f.col[0] = c.x; f.col[1] = c.y; f.col[2] = c.z;
+                        f.meta = (f.meta & ~3) | 2;
+                        const int psi = f.meta >> 4, pside = (f.meta >> 3) & 1;
+                        ray.org = {f.hit[0], f.hit[1], f.hit[2]};
+                        ray.dir = {f.rdir[0], f.rdir[1], f.rdir[2]};
+                        ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                        ray.list = sc.srf[psi].lst[pside * 2 + 1];
+                        ray.osi = psi; ray.oflg = pside;
+                        ray.ploc = {f.loc[0], f.loc[1], f.loc[2]};
+                        mode = 0;
+                        if (COUNT) cnt.reflect++;
+                    }
+                    else
+                    {
+                        ret = c;
+                        sp--;
+                    }
+                }
+                else
+                {
+                    /* RF_ret + RF_mix 3868-3908 */
+                    ret.x = ret.x * f.c_rfl + f.col[0];
+                    ret.y = ret.y * f.c_rfl + f.col[1];
+                    ret.z = ret.z * f.c_rfl + f.col[2];
+                    sp--;
+                }
+            }
+        }
+    }
+
+    /* XX_end 5161-5343: clamp, FSAA reduce, gamma, pack */
+    float cr = clamp1(ret.x), cg = clamp1(ret.y), cb = clamp1(ret.z);
+    if (fsaa >= 1)
+    {
+        cr = cr * 0.5f; cg = cg * 0.5f; cb = cb * 0.5f;
+        cr = cr + __shfl_down(cr, 1); cg = cg + __shfl_down(cg, 1); cb = cb + __shfl_down(cb, 1);
+    }
+    if (fsaa >= 2)
+    {
+        cr = cr * 0.5f; cg = cg * 0.5f; cb = cb * 0.5f;
+        cr = cr + __shfl_down(cr, 2); cg = cg + __shfl_down(cg, 2); cb = cb + __shfl_down(cb, 2);
+    }
+    if (inside && k == 0)
+    {
+        if (fr.ctx_flags & QR_PROP_GAMMA)
+        {
+            cr = __builtin_sqrtf(cr); cg = __builtin_sqrtf(cg); cb = __builtin_sqrtf(cb);
+        }
+        cr = cr * fr.clamp; cg = cg * fr.clamp; cb = cb * fr.clamp;
+        const u32 p = (((u32)cvt_near(cr) & fr.cmask) << 16) |
+                      (((u32)cvt_near(cg) & fr.cmask) << 8) |
+                       ((u32)cvt_near(cb) & fr.cmask);
+        frame[(size_t)y * fr.frm_w + x] = p;
+        if (ids != nullptr) ids[(size_t)y * fr.frm_w + x] = hit_id;
+    }
+
+    if (COUNT)
+    {
+        /* one atomic per wave and counter */
+        unsigned long long v[4] = { cnt.primary, cnt.shadow, cnt.reflect, cnt.refract };
+        for (int i = 0; i < 4; i++)
+        {
+            unsigned long long s = v[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+            if (lane == 0 && s != 0) atomicAdd(&counters[i], s);
+        }
+    }
+}
+
+#endif /* QR_KERNEL_HPP */

@@ -1,0 +1,61 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/qrhip.h declares
+(no compute calls here - there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_blob
+
+
+def test_library_exports_every_declared_symbol(qr):
+    header = open(os.path.join(ROOT, "include", "qrhip.h")).read()
+    declared = set(re.findall(r"\b(qr_[a-z0-9_]+)\s*\(", header))
+    L = qr.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"libqrhip.so lacks {missing}"
+    assert set(qr.ABI_SYMBOLS) <= declared
+
+
+def test_version_and_kernel_name(qr):
+    L = qr.lib()
+    assert b"gfx950" in L.qr_version()
+    assert L.qr_kernel_name() == b"qr_render_kernel"
+
+
+def test_upload_rejects_malformed_snapshot(qr):
+    blob = bytearray(load_blob("demo01_160"))
+    blob[0] ^= 0xFF                                   # break the magic
+    with pytest.raises(qr.QrError):
+        qr.Scene(bytes(blob))
+
+
+def test_upload_rejects_out_of_range_index(qr):
+    import struct
+    blob = bytearray(load_blob("demo01_160"))
+    off_tiles = struct.unpack_from("<I", blob, 4 * 15)[0]
+    struct.pack_into("<i", blob, off_tiles, 1 << 30)  # tile head far outside the element array
+    with pytest.raises(qr.QrError):
+        qr.Scene(bytes(blob))
+
+
+def test_no_gpu_fails_loudly(qr):
+    """Without a usable HIP device the product path raises; it never falls back to CPU code."""
+    if qr.lib().qr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(qr.QrError):
+        qr.Scene(load_blob("demo01_160"))
+
+
+def test_flatten_rejects_bad_abi(qr):
+    class Abi(ctypes.Structure):
+        _fields_ = [("struct_size", ctypes.c_uint32), ("quads", ctypes.c_uint32), ("pointer_bits", ctypes.c_uint32),
+                    ("address_bits", ctypes.c_uint32), ("element_bits", ctypes.c_uint32), ("endian", ctypes.c_uint32),
+                    ("reserved", ctypes.c_uint32 * 2)]
+    L = qr.lib()
+    abi = Abi(ctypes.sizeof(Abi), 8, 64, 64, 64, 0)   # fp64 build: unsupported
+    dummy = ctypes.create_string_buffer(8192)
+    blob = ctypes.c_void_p(); size = ctypes.c_uint64()
+    rc = L.qr_flatten(dummy, ctypes.byref(abi), ctypes.byref(blob), ctypes.byref(size))
+    assert rc == -2

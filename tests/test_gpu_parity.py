@@ -1,0 +1,91 @@
+"""GPU suite: the HIP backend (through the C ABI) against the oracle and the reference's golden frames.
+
+Bar: bit-exact 0x00RRGGBB pixels, bit-exact primary hit-id buffers, equal ray counts.
+"""
+import numpy as np
+import pytest
+
+from conftest import MANIFEST, SMALL_CASES, BIG_CASES, load_blob, load_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_frame(qr, blob, **kw):
+    import torch
+    scn = qr.Scene(blob)
+    for k, v in kw.items():
+        getattr(scn, k)(*v)
+    frame = scn.new_frame()
+    ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids)
+    torch.cuda.synchronize()
+    out = frame.cpu().numpy().view(np.uint32)
+    return scn, out, ids.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_gpu_matches_reference_frame_and_oracle(qr, oracle, name):
+    blob = load_blob(name)
+    ref = load_frame(name) & 0xFFFFFF
+    scn, out, ids = _gpu_frame(qr, blob)
+    diff = int((out != ref).sum())
+    assert diff == 0, f"{name}: {diff} pixels differ from the reference frame"
+    o_frame, o_ids, o_counts = oracle.render(blob, threads=8, want_ids=True)
+    assert (out == o_frame).all()
+    assert (ids == o_ids).all(), "primary hit-id buffer differs from the oracle"
+    _, c = scn.render_count()
+    assert c.as_dict() == o_counts
+
+
+@pytest.mark.parametrize("name", BIG_CASES)
+def test_gpu_full_size_hash_and_oracle(qr, oracle, name):
+    """BASELINE.json configs at full size: reference frame hash + pixel equality with the oracle."""
+    blob = load_blob(name)
+    scn, out, ids = _gpu_frame(qr, blob)
+    assert oracle.frame_hash(out) == int(MANIFEST[name]["hash"], 16)
+    o_frame, o_ids, o_counts = oracle.render(blob, threads=16, want_ids=True)
+    assert (out == o_frame).all()
+    assert (ids == o_ids).all()
+    _, c = scn.render_count()
+    assert c.as_dict() == o_counts
+
+
+def test_gpu_depth_override_matches_oracle(qr, oracle):
+    blob = load_blob("demo02_160_gf_aa4")
+    for depth in (0, 1, 2, 5):
+        scn, out, _ = _gpu_frame(qr, blob, set_depth=(depth,))
+        o_frame, _, _ = oracle.render(blob, depth=depth, threads=8)
+        assert (out == o_frame).all(), f"depth {depth}"
+
+
+def test_gpu_row_interleave_and_tile_row_sharding_compose(qr):
+    """index/thnum slices and round-robin tile-row shards each compose to the whole frame
+    (idempotence of the partition; this is the multi-GPU decomposition)."""
+    import torch
+    blob = load_blob("c1_demo01_640x480")
+    scn, whole, _ = _gpu_frame(qr, blob)
+    acc = torch.zeros((scn.height, scn.width), dtype=torch.int32, device="cuda")
+    for idx in range(3):
+        scn.set_rows(0, scn.height, idx, 3)
+        scn.render(acc)
+    torch.cuda.synchronize()
+    assert (acc.cpu().numpy().view(np.uint32) == whole).all()
+    acc.zero_()
+    for r in range(4):
+        scn.set_tile_rows(r, 4)
+        scn.render(acc)
+    torch.cuda.synchronize()
+    assert (acc.cpu().numpy().view(np.uint32) == whole).all()
+
+
+def test_gpu_render_host_matches_device_path(qr):
+    blob = load_blob("demo03_160")
+    scn, out, _ = _gpu_frame(qr, blob)
+    assert (scn.render_host() == out).all()
+
+
+def test_gpu_is_deterministic(qr):
+    blob = load_blob("demo02_160_gf_t5000")
+    _, a, _ = _gpu_frame(qr, blob)
+    _, b, _ = _gpu_frame(qr, blob)
+    assert (a == b).all()
