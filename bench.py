@@ -199,8 +199,10 @@ def main():
         value = total_rays / dt / 1e6
         bw = {0: 32, 1: 16, 2: 8}[scn.info.fsaa]
         n_wg = ((W + bw - 1) // bw) * n_groups
-        scene_bytes = scn.info.device_bytes
-        alg_bytes = 4 * W * H + n_wg * scene_bytes      # frame write + scene read per workgroup
+        # bytes_alg = 4*W*H (frame write) + n_workgroups * scene_bytes, scene_bytes = the
+        # surface + material + light records one workgroup needs (256 / 128 / 64 B records of qr_scene.h)
+        scene_bytes = scn.info.n_srf * 256 + scn.info.n_mat * 128 + scn.info.n_lgt * 64
+        alg_bytes = 4 * W * H + n_wg * scene_bytes
         roofline = dict(bound="hbm", achieved=alg_bytes / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
                         kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms,

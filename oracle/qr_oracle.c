@@ -124,12 +124,16 @@ typedef struct ctx_t
     int   xmisc_ptr;
     /* primary hit id (ours, not in the reference) */
     int   hit_id;
+    /* deferred-shading mode (ours): the pending final hit of this context */
+    int   pend_si, pend_side, pend_kind, in_final;
+    float pend_t, pend_loc[3];
 } ctx_t;
 
 typedef struct tracer_t
 {
     const scene_t *s;
     int depth;              /* inf_DEPTH, decremented around child packets */
+    int deferred;           /* shade only the final hit of a list walk (see qro_render) */
     counts_t cnt;
 } tracer_t;
 
@@ -393,6 +397,21 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
         return 1;
     }
 
+    /*
+     * Deferred mode (NOT how the reference works; it is the claim the HIP
+     * backend relies on, checked here on the CPU): shading has no effect on
+     * the list walk and fully overwrites the lane's colour, so only the last
+     * hit that passes the depth test needs shading.  Keep the depth write
+     * (PAINT_FRAG) and remember the hit.
+     */
+    if (T->deferred && !c->in_final)
+    {
+        c->t_buf = c->t_val;
+        c->pend_si = si; c->pend_side = side; c->pend_kind = kind; c->pend_t = c->t_val;
+        c->pend_loc[0] = c->nw[sh + 0]; c->pend_loc[1] = c->nw[sh + 1]; c->pend_loc[2] = c->nw[sh + 2];
+        return 0;
+    }
+
     /* surface-kind specific part: texture coords + normal */
     if (kind == NRM_PLANE)
     {
@@ -533,7 +552,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 ch.t_min = 0.0f;
                 ch.org[0] = c->hit[0]; ch.org[1] = c->hit[1]; ch.org[2] = c->hit[2];
                 ch.ray[0] = c->nw[0];  ch.ray[1] = c->nw[1];  ch.ray[2] = c->nw[2];
-                ch.local_obj = QR_NULL;
+                ch.local_obj = QR_NULL; ch.pend_si = QR_NULL;
                 T->depth -= 1;
                 T->cnt.shadow++;
                 trace_list(T, &ch, &c->nrm[3], v->elm[le].data);
@@ -757,7 +776,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                     ch.t_min = 0.0f;
                     ch.org[0] = c->hit[0]; ch.org[1] = c->hit[1]; ch.org[2] = c->hit[2];
                     ch.ray[0] = c->nw[0];  ch.ray[1] = c->nw[1];  ch.ray[2] = c->nw[2];
-                    ch.local_obj = QR_NULL;
+                    ch.local_obj = QR_NULL; ch.pend_si = QR_NULL;
                     ch.hit_id = -1;
                     T->depth -= 1;
                     T->cnt.refract++;
@@ -859,7 +878,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 ch.t_min = 0.0f;
                 ch.org[0] = c->hit[0]; ch.org[1] = c->hit[1]; ch.org[2] = c->hit[2];
                 ch.ray[0] = c->nw[0];  ch.ray[1] = c->nw[1];  ch.ray[2] = c->nw[2];
-                ch.local_obj = QR_NULL;
+                ch.local_obj = QR_NULL; ch.pend_si = QR_NULL;
                 ch.hit_id = -1;
                 T->depth -= 1;
                 T->cnt.reflect++;
@@ -1140,6 +1159,22 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
 
         e = el->next;
     }
+
+    if (T->deferred && c->pend_si != QR_NULL)
+    {
+        /* shade the final hit once, from the same inputs the eager path had */
+        const qr_surface *s = &v->srf[c->pend_si];
+        const int sh = s->shift ? 3 : 0;
+        const float t = c->pend_t;
+        float x;
+        x = c->ray[0] * t; c->hit[0] = x + c->org[0];
+        x = c->ray[1] * t; c->hit[1] = x + c->org[1];
+        x = c->ray[2] * t; c->hit[2] = x + c->org[2];
+        c->nw[sh + 0] = c->pend_loc[0]; c->nw[sh + 1] = c->pend_loc[1]; c->nw[sh + 2] = c->pend_loc[2];
+        c->t_val = t;
+        c->in_final = 1;
+        shade(T, c, c->pend_si, c->pend_side, c->pend_kind);
+    }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1166,6 +1201,7 @@ static void sample(tracer_t *T, int x, int y, int k, float col[3], int *hit_id)
     c.param_flg = fr->ctx_flags;
     c.param_obj = QR_NULL;
     c.local_obj = QR_NULL;
+    c.pend_si = QR_NULL;
     c.hit_id = -1;
 
     /* primary ray 1287-1322 */
@@ -1237,10 +1273,12 @@ static u32 pixel(tracer_t *T, int x, int y, int *hit_id)
  * (y % thnum) == index; pass 0, frm_h, and the snapshot's index/thnum (or 0,1).
  * ids (optional) receives (surface<<1|side) of the visible primary hit.
  * counts (optional) = {primary, shadow, reflect, refract} rays.
+ * deferred != 0: shade only the final hit of each list walk (same pixels, fewer
+ * rays: the "useful ray" count the HIP backend also reports).
  */
-int qro_render(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
-               int depth, int row_begin, int row_end, int index, int thnum,
-               int threads, uint64_t counts[4])
+int qro_render2(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
+                int depth, int row_begin, int row_end, int index, int thnum,
+                int threads, uint64_t counts[4], int deferred)
 {
     scene_t S;
     int rc = qr_scene_view_init(&S.v, blob, size);
@@ -1262,7 +1300,7 @@ int qro_render(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
         tracer_t T;
         int x;
         if ((y % thnum) != index) continue;
-        T.s = &S; T.depth = S.depth;
+        T.s = &S; T.depth = S.depth; T.deferred = deferred;
         memset(&T.cnt, 0, sizeof(T.cnt));
         for (x = 0; x < w; x++)
         {
@@ -1275,6 +1313,14 @@ int qro_render(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
     }
     if (counts) { counts[0] = c0; counts[1] = c1; counts[2] = c2; counts[3] = c3; }
     return 0;
+}
+
+/* reference semantics: every hit that passes the depth test is shaded (overdraw) */
+int qro_render(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
+               int depth, int row_begin, int row_end, int index, int thnum,
+               int threads, uint64_t counts[4])
+{
+    return qro_render2(blob, size, frame, ids, depth, row_begin, row_end, index, thnum, threads, counts, 0);
 }
 
 int qro_info(const void *blob, uint64_t size, int32_t out[8])

@@ -165,11 +165,11 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     e = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long));
-    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-    hipEventCreate(&s->ev0);
-    hipEventCreate(&s->ev1);
+    if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    (void)hipEventCreate(&s->ev0);
+    (void)hipEventCreate(&s->ev1);
     s->blob_bytes = total;
 
     uint8_t *d = (uint8_t *)s->d_blob;
@@ -192,11 +192,11 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
 extern "C" int qr_scene_destroy(qr_device_scene *s)
 {
     if (s == nullptr) return QR_OK;
-    hipSetDevice(s->device);
-    hipEventDestroy(s->ev0);
-    hipEventDestroy(s->ev1);
-    hipFree(s->d_counters);
-    hipFree(s->d_blob);
+    (void)hipSetDevice(s->device);
+    (void)hipEventDestroy(s->ev0);
+    (void)hipEventDestroy(s->ev1);
+    (void)hipFree(s->d_counters);
+    (void)hipFree(s->d_blob);
     delete s;
     return QR_OK;
 }
@@ -242,6 +242,7 @@ extern "C" int qr_scene_set_tile_rows(qr_device_scene *s, int first, int stride)
     const int total = (s->sc.fr.frm_h + 7) / 8;
     if (stride <= 0 || first < 0) return qr_fail(QR_ERR_ARG, "bad tile-row selection");
     s->sc.row_begin = 0; s->sc.row_end = s->sc.fr.frm_h;
+    s->sc.index = 0; s->sc.thnum = 1;
     s->sc.group_first = first; s->sc.group_stride = stride;
     s->sc.n_groups = first < total ? (total - first + stride - 1) / stride : 0;
     return QR_OK;
@@ -322,7 +323,7 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
     hipError_t e = launch<false>(s, d_frame, nullptr, nullptr);
     std::vector<uint32_t> tmp((size_t)w * h);
     if (e == hipSuccess) e = hipMemcpy(tmp.data(), d_frame, (size_t)w * h * 4, hipMemcpyDeviceToHost);
-    hipFree(d_frame);
+    (void)hipFree(d_frame);
     if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     /* copy only the rows this call owns, honouring a negative stride (bottom-up
      * frames, engine.cpp:2814-2850) */

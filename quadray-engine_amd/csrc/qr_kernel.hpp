@@ -103,8 +103,36 @@ __device__ __forceinline__ void  vset(V3 &v, int i, float f)
 __device__ __forceinline__ int  ax_map(u32 axes, int n) { return (int)((axes >> (2 * n)) & 3); }
 __device__ __forceinline__ u32  ax_sgn(u32 axes, int n) { return ((axes >> (8 + n)) & 1) ? 0x80000000u : 0u; }
 
+/*
+ * Wave-uniform records are read through the CONSTANT address space: with a
+ * uniform (readfirstlane-derived) index the backend then selects s_load_dword*
+ * into SGPRs instead of 64 identical vector loads.  The arrays are never written
+ * while a launch is in flight.
+ */
+#define QR_CONST __attribute__((address_space(4)))
+typedef const QR_CONST qr_surface  *SrfP;
+typedef const QR_CONST qr_elem     *ElmP;
+typedef const QR_CONST qr_material *MatP;
+typedef const QR_CONST qr_light    *LgtP;
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ SrfP c_srf(const DevScene &sc) { return (SrfP)sc.srf; }
+__device__ __forceinline__ ElmP c_elm(const DevScene &sc) { return (ElmP)sc.elm; }
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ qr_elem ld_elem(ElmP p)
+{
+    qr_elem e;
+    e.simd = p->simd; e.data = p->data; e.next = p->next; e.kind = p->kind;
+    return e;
+}
+
+__device__ __forceinline__ float sci_at(SrfP s, int i) { return i == 0 ? s->sci[0] : i == 1 ? s->sci[1] : s->sci[2]; }
+
 /* 3x3 transform, tracer.cpp:1447-1479 order */
-__device__ __forceinline__ V3 xform(const qr_surface *__restrict__ s, int has_trm, V3 in)
+template <typename SP>
+__device__ __forceinline__ V3 xform(SP s, int has_trm, V3 in)
 {
     float x4 = s->tci[0] * in.x;
     float x5 = s->tcj[1] * in.y;
@@ -162,7 +190,7 @@ struct Walk
 /* all of `s`, `si` and the clipper list are wave-uniform                    */
 /* ------------------------------------------------------------------------ */
 
-__device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__restrict__ s,
+__device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
                                      const Ray &r, Walk &w, float t, int side, bool m)
 {
     const int has_trm = s->has_trm;
@@ -209,15 +237,15 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__res
             float r4;
             x2 = 0.0f;
             x1 = u2f((f2u(vget(df, mi)) & sm) ^ f2u(one));
-            x3 = vget(*(const V3 *)s->sci, mi);
+            x3 = sci_at(s,mi);
             r4 = one;
             if (conic != 2)
             {
                 x2 = u2f((f2u(vget(df, mj)) & sm) ^ f2u(one));
-                x3 = x3 + vget(*(const V3 *)s->sci, mj);
+                x3 = x3 + sci_at(s,mj);
                 r4 = r4 + one;
             }
-            x3 = x3 / vget(*(const V3 *)s->sci, mk);
+            x3 = x3 / sci_at(s,mk);
             x3 = fxor(x3, sm);
             float y6 = x3;
             x3 = __builtin_sqrtf(x3);
@@ -260,7 +288,7 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__res
         while (e != QR_NULL)
         {
             e = __builtin_amdgcn_readfirstlane(e);
-            const qr_elem el = sc.elm[e];
+            const qr_elem el = ld_elem(c_elm(sc) + e);
             const int enext = el.next;
             if (el.simd == QR_NULL)
             {
@@ -269,7 +297,7 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__res
                 e = enext;
                 continue;
             }
-            const qr_surface *__restrict__ k = &sc.srf[el.simd];
+            SrfP k = c_srf(sc) + el.simd;
             const int ktag = k->srf_t[3];
             const int ktrm = k->has_trm;
             bool have_vec = false;
@@ -362,7 +390,7 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const qr_surface *__res
 /* ------------------------------------------------------------------------ */
 
 template <bool SHADOW>
-__device__ __noinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
+__device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
 {
     Walk w;
     w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
@@ -379,9 +407,9 @@ __device__ __noinline__ void walk_list(const DevScene &sc, int head, const Ray &
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
-        const qr_elem el = sc.elm[e];
+        const qr_elem el = ld_elem(c_elm(sc) + e);
         const int si = el.simd;
-        const qr_surface *__restrict__ s = &sc.srf[si];
+        SrfP s = c_srf(sc) + si;
         const int tag = s->srf_t[3];
         const int has_trm = s->has_trm;
         const int sh = s->shift;
@@ -520,13 +548,13 @@ __device__ __noinline__ void walk_list(const DevScene &sc, int head, const Ray &
                     const u32 axes = s->axes;
                     const int mi = ax_map(axes, 0), mk = ax_map(axes, 2);
                     float x0, x1, x2, x3, x4, x5, x6, x7;
-                    x1 = vget(ry, mi); x5 = vget(df, mi); x3 = vget(*(const V3 *)s->sci, mi);
-                    x2 = vget(ry, mk); x6 = vget(df, mk); x4 = vget(*(const V3 *)s->sci, mk);
+                    x1 = vget(ry, mi); x5 = vget(df, mi); x3 = sci_at(s,mi);
+                    x2 = vget(ry, mk); x6 = vget(df, mk); x4 = sci_at(s,mk);
                     x0 = x5; x7 = x6;
                     x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
                     x5 = fabs_bits(x5);
                     x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
-                    x4 = vget(*(const V3 *)s->sci, mk);
+                    x4 = sci_at(s,mk);
                     x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
                     x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
                     a = x1; b = x3; c = x0; d = x5;

