@@ -13,7 +13,7 @@ import gzip
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqrhip.so")
+LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR_LIB: A/B experiment builds
 
 # every symbol include/qrhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

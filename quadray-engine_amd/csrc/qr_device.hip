@@ -147,20 +147,84 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     /* one device allocation; each array padded by one zero record so that
      * masked-off lanes may read index 0 of an empty array */
     size_t o_srf = 0;
-    size_t o_mat = pad16(o_srf + (size_t)(n_srf + 1) * sizeof(qr_surface));
+    size_t o_shd = pad16(o_srf + (size_t)(n_srf + 1) * sizeof(DSurf));
+    size_t o_mat = pad16(o_shd + (size_t)(n_srf + 1) * sizeof(DShade));
     size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
     size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
     size_t o_til = pad16(o_elm + (size_t)(n_elm + 1) * sizeof(qr_elem));
     size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
-    size_t total = pad16(o_tex + (size_t)(n_tex + 1) * 4);
+    /* block schedule */
+    const int bwid = fr.fsaa == 0 ? 32 : fr.fsaa == 1 ? 16 : 8;
+    const int nbx = (fr.frm_w + bwid - 1) / bwid, nby = (fr.frm_h + 7) / 8;
+    if (nbx > 0xFFFF || nby > 0xFFFF) return qr_fail(QR_ERR_ARG, "frame too large");
+    std::vector<uint32_t> order;
+    {
+        std::vector<uint32_t> heavy, light;
+        for (int by = 0; by < nby; by++)
+            for (int bx = 0; bx < nbx; bx++)
+            {
+                const int tx = (bx * bwid) / fr.tile_w, ty = (by * 8) / fr.tile_h;
+                bool hv = false;
+                if (tx < fr.tls_row && ty < fr.tls_col)
+                    for (int e = v.tiles[ty * fr.tls_row + tx]; e != QR_NULL && !hv; e = v.elm[e].next)
+                    {
+                        const qr_surface &q = v.srf[v.elm[e].simd];
+                        if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+                        for (int k = 0; k < 2; k++)
+                            if ((q.props[k] & QR_PROP_REFLECT) || !(q.props[k] & QR_PROP_OPAQUE)) hv = true;
+                    }
+                (hv ? heavy : light).push_back((uint32_t)bx | ((uint32_t)by << 16));
+            }
+        order = heavy;
+        order.insert(order.end(), light.begin(), light.end());
+    }
+    size_t o_ord = pad16(o_tex + (size_t)(n_tex + 1) * 4);
+    size_t total = pad16(o_ord + order.size() * 4 + 16);
 
     std::vector<uint8_t> host(total, 0);
-    memcpy(host.data() + o_srf, v.srf, (size_t)n_srf * sizeof(qr_surface));
+    /* repack qr_surface (256 B, snapshot layout) into the device records:
+     * DSurf (128 B, hot part first) for the list walk, DShade for shading */
+    for (int i = 0; i < n_srf; i++)
+    {
+        const qr_surface &q = v.srf[i];
+        if (q.smask != QR_SMASK && q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX) { delete s; return qr_fail(QR_ERR_ARG, "surface smask is not the fp32 sign bit"); }
+        DSurf d; memset(&d, 0, sizeof(d));
+        DShade h; memset(&h, 0, sizeof(h));
+        for (int k = 0; k < 3; k++)
+        {
+            d.pos[k] = q.pos[k]; d.scj[k] = q.scj[k]; d.min[k] = q.min[k]; d.max[k] = q.max[k];
+            d.tci[k] = q.tci[k]; d.tcj[k] = q.tcj[k]; d.tck[k] = q.tck[k];
+        }
+        for (int k = 0; k < 4; k++) { d.sci[k] = q.sci[k]; h.lst[k] = q.lst[k]; }
+        d.clip = q.clip; d.d_eps = q.d_eps; d.t_eps = q.t_eps;
+        d.trnode = q.trnode;
+        d.props0 = q.props[0]; d.props1 = q.props[1];
+        h.mat[0] = q.mat[0] >= 0 ? q.mat[0] : 0; h.mat[1] = q.mat[1] >= 0 ? q.mat[1] : 0;
+        const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
+        uint32_t f = 0;
+        f |= q.minmax_t & 63u;
+        f |= ((uint32_t)q.conic & 3u) << 6;
+        f |= ((uint32_t)q.has_trm & 3u) << 8;
+        f |= (q.shift ? 1u : 0u) << 10;
+        f |= ((q.axes >> 0) & 3u) << 11; f |= ((q.axes >> 2) & 3u) << 13; f |= ((q.axes >> 4) & 3u) << 15;
+        f |= ((q.axes >> 8) & 7u) << 17;
+        f |= (real ? ((uint32_t)q.srf_t[0] & 3u) : 0u) << 20;
+        f |= ((uint32_t)q.srf_t[1] & 3u) << 22;
+        f |= ((uint32_t)q.srf_t[2] & 3u) << 24;
+        f |= (q.srf_t[3] < 0 ? 1u : 0u) << 26;
+        f |= (q.c_def != 0 ? 1u : 0u) << 28;
+        d.flags = f;
+        if ((q.conic & ~3) || (q.has_trm & ~3) || (q.srf_t[0] & ~3) || (q.srf_t[1] & ~3) || (q.srf_t[2] & ~3))
+        { delete s; return qr_fail(QR_ERR_ARG, "surface tag fields out of range"); }
+        memcpy(host.data() + o_srf + (size_t)i * sizeof(DSurf), &d, sizeof(d));
+        memcpy(host.data() + o_shd + (size_t)i * sizeof(DShade), &h, sizeof(h));
+    }
     memcpy(host.data() + o_mat, v.mat, (size_t)n_mat * sizeof(qr_material));
     memcpy(host.data() + o_lgt, v.lgt, (size_t)n_lgt * sizeof(qr_light));
     memcpy(host.data() + o_elm, v.elm, (size_t)n_elm * sizeof(qr_elem));
     memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
     memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
+    memcpy(host.data() + o_ord, order.data(), order.size() * 4);
 
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -173,18 +237,22 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     s->blob_bytes = total;
 
     uint8_t *d = (uint8_t *)s->d_blob;
-    s->sc.srf = (const qr_surface *)(d + o_srf);
+    s->sc.srf = (const DSurf *)(d + o_srf);
+    s->sc.shd = (const DShade *)(d + o_shd);
     s->sc.mat = (const qr_material *)(d + o_mat);
     s->sc.lgt = (const qr_light *)(d + o_lgt);
     s->sc.elm = (const qr_elem *)(d + o_elm);
     s->sc.tiles = (const int32_t *)(d + o_til);
     s->sc.texels = (const uint32_t *)(d + o_tex);
+    s->sc.order = (const uint32_t *)(d + o_ord);
+    s->sc.n_blocks = (int32_t)order.size();
     s->sc.fr = fr;
     s->sc.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
     s->sc.row_begin = 0; s->sc.row_end = fr.frm_h;
     s->sc.index = fr.index; s->sc.thnum = fr.thnum > 0 ? fr.thnum : 1;
     s->sc.group_first = 0; s->sc.group_stride = 1;
     s->sc.n_groups = (fr.frm_h + 7) / 8;
+    s->sc.dbg = getenv("QR_DBG") ? atoi(getenv("QR_DBG")) : 0;
     *out = s;
     return QR_OK;
 }
@@ -253,10 +321,16 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
 {
     const int fsaa = s->sc.fr.fsaa;
     const int bw = fsaa == 0 ? 32 : fsaa == 1 ? 16 : 8;
-    dim3 grid((s->sc.fr.frm_w + bw - 1) / bw, s->sc.n_groups, 1);
-    if (grid.x == 0 || grid.y == 0) return hipSuccess;
-    hipLaunchKernelGGL(qr_render_kernel<COUNT>, grid, dim3(QR_BLOCK), 0, st,
-                       s->sc, (uint32_t *)frame_dev, ids_dev, s->d_counters);
+    (void)bw;
+    dim3 grid(s->sc.n_blocks, 1, 1);
+    if (grid.x == 0 || s->sc.n_groups == 0) return hipSuccess;
+    /* register budget variant (waves per SIMD); QR_WAVES is a tuning knob for experiments */
+    static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
+                                    return (w == 2 || w == 3 || w == 4) ? w : QR_MIN_WAVES_PER_SIMD; }();
+    uint32_t *f = (uint32_t *)frame_dev;
+    if (waves == 4)      hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
+    else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<COUNT, 3>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
+    else                 hipLaunchKernelGGL((qr_render_kernel<COUNT, 2>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
     return hipGetLastError();
 }
 

@@ -14,16 +14,21 @@
  *     32x8 reference tile, so the four waves share the tile's object list.
  *   - WAVE-PACKET TRAVERSAL: lanes of a wave that walk the same list walk it
  *     together; the element index is wave-uniform, so element and surface
- *     records are fetched with scalar loads into SGPRs and only per-ray
- *     quantities live in VGPRs.  Lanes with different lists (secondary rays
- *     leaving different surfaces) are served group by group (__ballot /
- *     readfirstlane) - the wave-level analogue of the reference's
- *     CHECK_MASK NONE/FULL packet early-outs (rtbase.h:1209).
+ *     records are fetched with SCALAR loads (constant address space) into
+ *     SGPRs and only per-ray quantities live in VGPRs.  Lanes with different
+ *     lists (secondary rays leaving different surfaces) are served group by
+ *     group (__ballot / readfirstlane) - the wave-level analogue of the
+ *     reference's CHECK_MASK NONE/FULL packet early-outs (rtbase.h:1209).
+ *   - the walk is SOFTWARE PIPELINED: while element i is intersected, the
+ *     20-dword hot record of element i+1 and the list cell of element i+2 are
+ *     already in flight, so the two dependent scalar-load latencies per
+ *     element are off the critical path at 2-3 waves per SIMD.
  *   - DEFERRED SHADING: the reference shades every hit that passes the depth
  *     test while it walks a list (overdraw); shading has no effect on the walk
  *     and fully overwrites the lane's colour, so walking first (keeping the
  *     depth-test sequence) and shading only the final hit is bit-identical and
- *     costs one shading (and one set of shadow rays) per ray.
+ *     costs one shading (and one set of shadow rays) per ray
+ *     (checked on the CPU by tests/test_oracle.py::test_deferred_shading_*).
  *   - recursion (context stack, tracer.h:426-665) becomes a per-lane explicit
  *     stack of 16-dword frames evaluated in the reference's order
  *     (refraction child, then reflection child), so colour arithmetic keeps the
@@ -41,11 +46,61 @@
 #include "qr_scene.h"
 
 #define QR_BLOCK 256
+#ifndef QR_MAX_DEPTH
 #define QR_MAX_DEPTH 10           /* RT_STACK_DEPTH, tracer.h:46 */
+#endif
+#ifndef QR_PIPE
+#define QR_PIPE 0                 /* list-walk prefetch depth: 0 none, 1 next cell, 2 next cell + next record */
+#endif
+#ifndef QR_MIN_WAVES_PER_SIMD
+#define QR_MIN_WAVES_PER_SIMD 3   /* __launch_bounds__ 2nd argument: waves per SIMD */
+#endif
+
+typedef uint32_t u32;
+
+/*
+ * Device-side surface record (built by qr_scene_upload from qr_surface):
+ * 32 dwords, the first 20 ("hot") are everything the list walk needs for a
+ * surface without transform; one s_load_dwordx16 + one s_load_dwordx4.
+ */
+struct DSurf
+{
+    float pos[3]; u32 flags;        /*  0 */
+    float sci[4];                   /*  4 */
+    float scj[3]; int32_t clip;     /*  8 */
+    float min[3]; float d_eps;      /* 12 */
+    float max[3]; float t_eps;      /* 16 */
+    float tci[3]; int32_t trnode;   /* 20 */
+    float tcj[3]; int32_t props0;   /* 24 */
+    float tck[3]; int32_t props1;   /* 28 */
+};
+
+/* flags word of DSurf */
+#define DF_MINMAX(f)  ((f) & 63u)
+#define DF_CONIC(f)   (((f) >> 6) & 3u)
+#define DF_TRM(f)     (((f) >> 8) & 3u)
+#define DF_SHIFT(f)   (((f) >> 10) & 1u)
+#define DF_MAP(f, n)  (((f) >> (11 + 2 * (n))) & 3u)
+#define DF_SGN(f, n)  ((((f) >> (17 + (n))) & 1u) ? 0x80000000u : 0u)
+#define DF_SOLVER(f)  (((f) >> 20) & 3u)
+#define DF_NKIND(f)   (((f) >> 22) & 3u)
+#define DF_CKIND(f)   (((f) >> 24) & 3u)
+#define DF_ARRAY(f)   (((f) >> 26) & 1u)    /* tag < 0: array / trnode element */
+#define DF_CDEF(f)    (((f) >> 28) & 1u)
+#define QR_SMASK 0x80000000u
+
+/* per-surface data only shading needs */
+struct DShade
+{
+    int32_t mat[2];
+    int32_t lst[4];
+    int32_t pad[2];
+};
 
 struct DevScene
 {
-    const qr_surface  *__restrict__ srf;
+    const DSurf       *__restrict__ srf;
+    const DShade      *__restrict__ shd;
     const qr_material *__restrict__ mat;
     const qr_light    *__restrict__ lgt;
     const qr_elem     *__restrict__ elm;
@@ -56,9 +111,10 @@ struct DevScene
     int32_t row_begin, row_end;   /* rows rendered by this launch            */
     int32_t index, thnum;         /* reference row interleave                */
     int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
+    const uint32_t    *__restrict__ order;  /* block schedule: bx | by << 16, heavy tiles first */
+    int32_t n_blocks;
+    int32_t dbg;                  /* timing experiments only (QR_DBG): 1 no shadow walks, 2 no lights */
 };
-
-typedef uint32_t u32;
 
 /* ------------------------------------------------------------------------ */
 /* lane primitives (same definitions as the oracle)                          */
@@ -100,9 +156,6 @@ __device__ __forceinline__ void  vset(V3 &v, int i, float f)
 #define FLAG_SIDE 1
 #define FLAG_PASS_THRU 2
 
-__device__ __forceinline__ int  ax_map(u32 axes, int n) { return (int)((axes >> (2 * n)) & 3); }
-__device__ __forceinline__ u32  ax_sgn(u32 axes, int n) { return ((axes >> (8 + n)) & 1) ? 0x80000000u : 0u; }
-
 /*
  * Wave-uniform records are read through the CONSTANT address space: with a
  * uniform (readfirstlane-derived) index the backend then selects s_load_dword*
@@ -110,10 +163,8 @@ __device__ __forceinline__ u32  ax_sgn(u32 axes, int n) { return ((axes >> (8 + 
  * while a launch is in flight.
  */
 #define QR_CONST __attribute__((address_space(4)))
-typedef const QR_CONST qr_surface  *SrfP;
-typedef const QR_CONST qr_elem     *ElmP;
-typedef const QR_CONST qr_material *MatP;
-typedef const QR_CONST qr_light    *LgtP;
+typedef const QR_CONST DSurf   *SrfP;
+typedef const QR_CONST qr_elem *ElmP;
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
@@ -128,23 +179,37 @@ __device__ __forceinline__ qr_elem ld_elem(ElmP p)
     return e;
 }
 
-__device__ __forceinline__ float sci_at(SrfP s, int i) { return i == 0 ? s->sci[0] : i == 1 ? s->sci[1] : s->sci[2]; }
-
-/* 3x3 transform, tracer.cpp:1447-1479 order */
-template <typename SP>
-__device__ __forceinline__ V3 xform(SP s, int has_trm, V3 in)
+/* the hot part of a surface record, held in SGPRs */
+struct SV
 {
-    float x4 = s->tci[0] * in.x;
-    float x5 = s->tcj[1] * in.y;
-    float x6 = s->tck[2] * in.z;
+    SrfP p;                         /* fields are scalar-loaded where they are used:
+                                       holding all 20 hot dwords in SGPRs at once costs
+                                       ~130 SGPR spills (measured slower) */
+};
+
+__device__ __forceinline__ SV ld_hot(SrfP p)
+{
+    SV s;
+    s.p = p;
+    return s;
+}
+
+__device__ __forceinline__ float sci_at(const SV &s, int i) { return i == 0 ? s.p->sci[0] : i == 1 ? s.p->sci[1] : s.p->sci[2]; }
+
+/* 3x3 transform, tracer.cpp:1447-1479 order; matrix rows come from the cold part */
+__device__ __forceinline__ V3 xform(SrfP p, int has_trm, V3 in)
+{
+    float x4 = p->tci[0] * in.x;
+    float x5 = p->tcj[1] * in.y;
+    float x6 = p->tck[2] * in.z;
     if (has_trm != 1)
     {
-        x4 = x4 + s->tci[1] * in.y;
-        x4 = x4 + s->tci[2] * in.z;
-        x5 = x5 + s->tcj[0] * in.x;
-        x5 = x5 + s->tcj[2] * in.z;
-        x6 = x6 + s->tck[0] * in.x;
-        x6 = x6 + s->tck[1] * in.y;
+        x4 = x4 + p->tci[1] * in.y;
+        x4 = x4 + p->tci[2] * in.z;
+        x5 = x5 + p->tcj[0] * in.x;
+        x5 = x5 + p->tcj[2] * in.z;
+        x6 = x6 + p->tck[0] * in.x;
+        x6 = x6 + p->tck[1] * in.y;
     }
     V3 o; o.x = x4; o.y = x5; o.z = x6;
     return o;
@@ -187,14 +252,15 @@ struct Walk
 
 /* ------------------------------------------------------------------------ */
 /* CC_clp, tracer.cpp:1597-2160                                              */
-/* all of `s`, `si` and the clipper list are wave-uniform                    */
+/* `s` and the clipper list are wave-uniform                                 */
 /* ------------------------------------------------------------------------ */
 
-__device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
+__device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
                                      const Ray &r, Walk &w, float t, int side, bool m)
 {
-    const int has_trm = s->has_trm;
-    const int sh = s->shift;
+    const u32 fl = s.p->flags;
+    const int has_trm = (int)DF_TRM(fl);
+    const int sh = (int)DF_SHIFT(fl);
     float x4, x5, x6;
 
     m = m && cgt(w.tbuf, t);
@@ -212,46 +278,45 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
     }
     else
     {
-        x4 = x4 - s->pos[0]; w.nxyz.x = x4;
-        x5 = x5 - s->pos[1]; w.nxyz.y = x5;
-        x6 = x6 - s->pos[2]; w.nxyz.z = x6;
+        x4 = x4 - s.p->pos[0]; w.nxyz.x = x4;
+        x5 = x5 - s.p->pos[1]; w.nxyz.y = x5;
+        x6 = x6 - s.p->pos[2]; w.nxyz.z = x6;
     }
 
     /* conic singularity solver, 1706-1856 */
-    const int conic = s->conic;
+    const int conic = (int)DF_CONIC(fl);
     if (conic != 0)
     {
-        const u32 axes = s->axes;
-        const int mi = ax_map(axes, 0), mj = ax_map(axes, 1), mk = ax_map(axes, 2);
+        const int mi = (int)DF_MAP(fl, 0), mj = (int)DF_MAP(fl, 1), mk = (int)DF_MAP(fl, 2);
         V3 nw = sh ? w.nijk : w.nxyz;
         V3 df = sh ? w.dijk : w.dxyz;
         float x0, x1, x2, x3;
         x1 = vget(nw, mi); x1 = x1 * x1; x0 = x1;
         if (conic != 2) { x2 = vget(nw, mj); x2 = x2 * x2; x0 = x0 + x2; }
         x3 = vget(nw, mk); x3 = x3 * x3; x0 = x0 + x3;
-        bool hm = clt(x0, s->t_eps) && (w.dmask != 0);
+        bool hm = clt(x0, s.p->t_eps) && (w.dmask != 0);
         if (hm)
         {
-            const u32 sm = s->smask;
+            const u32 sm = QR_SMASK;
             const float one = 1.0f;
             float r4;
             x2 = 0.0f;
             x1 = u2f((f2u(vget(df, mi)) & sm) ^ f2u(one));
-            x3 = sci_at(s,mi);
+            x3 = sci_at(s, mi);
             r4 = one;
             if (conic != 2)
             {
                 x2 = u2f((f2u(vget(df, mj)) & sm) ^ f2u(one));
-                x3 = x3 + sci_at(s,mj);
+                x3 = x3 + sci_at(s, mj);
                 r4 = r4 + one;
             }
-            x3 = x3 / sci_at(s,mk);
+            x3 = x3 / sci_at(s, mk);
             x3 = fxor(x3, sm);
             float y6 = x3;
             x3 = __builtin_sqrtf(x3);
             y6 = y6 + r4;
             r4 = rsq(y6);
-            r4 = r4 * s->t_eps;
+            r4 = r4 * s.p->t_eps;
             x1 = x1 * r4; x2 = x2 * r4; x3 = x3 * r4;
 
             const u32 tside = side ? sm : 0u;
@@ -270,20 +335,20 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
     }
 
     /* axis min/max, 1874-1927 */
-    const u32 mm = s->minmax_t;
-    if (mm & 0x01) m = m && cle(s->min[0], x4);
-    if (mm & 0x08) m = m && cge(s->max[0], x4);
-    if (mm & 0x02) m = m && cle(s->min[1], x5);
-    if (mm & 0x10) m = m && cge(s->max[1], x5);
-    if (mm & 0x04) m = m && cle(s->min[2], x6);
-    if (mm & 0x20) m = m && cge(s->max[2], x6);
+    const u32 mm = DF_MINMAX(fl);
+    if (mm & 0x01) m = m && cle(s.p->min[0], x4);
+    if (mm & 0x08) m = m && cge(s.p->max[0], x4);
+    if (mm & 0x02) m = m && cle(s.p->min[1], x5);
+    if (mm & 0x10) m = m && cge(s.p->max[1], x5);
+    if (mm & 0x04) m = m && cle(s.p->min[2], x6);
+    if (mm & 0x20) m = m && cge(s.p->max[2], x6);
 
     /* custom clipping, 1931-2151 */
-    int e = s->clip;
+    int e = s.p->clip;
     if (e != QR_NULL && __any(m))
     {
         int redx = QR_NULL;
-        const int local_lst = s->trnode;
+        const int local_lst = s.p->trnode;
         bool c_acc = false;
         while (e != QR_NULL)
         {
@@ -293,30 +358,32 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
             if (el.simd == QR_NULL)
             {
                 if (el.data > 0) { m = !m && c_acc; }
-                else             { c_acc = m; m = (s->c_def != 0); }
+                else             { c_acc = m; m = DF_CDEF(fl) != 0; }
                 e = enext;
                 continue;
             }
-            SrfP k = c_srf(sc) + el.simd;
-            const int ktag = k->srf_t[3];
-            const int ktrm = k->has_trm;
+            SrfP kp = c_srf(sc) + el.simd;
+            const u32 kf = kp->flags;
+            const int ktrm = (int)DF_TRM(kf);
+            const bool karr = DF_ARRAY(kf) != 0;
+            const float kp0 = kp->pos[0], kp1 = kp->pos[1], kp2 = kp->pos[2];
             bool have_vec = false;
-            if (ktag >= 0)
+            if (!karr)
             {
                 if (redx != QR_NULL)
                 {
-                    w.cijk.x = w.cxyz.x - k->pos[0];
-                    w.cijk.y = w.cxyz.y - k->pos[1];
-                    w.cijk.z = w.cxyz.z - k->pos[2];
+                    w.cijk.x = w.cxyz.x - kp0;
+                    w.cijk.y = w.cxyz.y - kp1;
+                    w.cijk.z = w.cxyz.z - kp2;
                     if (e == redx) redx = QR_NULL;
                     have_vec = true;
                 }
             }
             else if (el.simd == local_lst)
             {
-                w.cxyz.x = w.nijk.x + s->pos[0];
-                w.cxyz.y = w.nijk.y + s->pos[1];
-                w.cxyz.z = w.nijk.z + s->pos[2];
+                w.cxyz.x = w.nijk.x + s.p->pos[0];
+                w.cxyz.y = w.nijk.y + s.p->pos[1];
+                w.cxyz.z = w.nijk.z + s.p->pos[2];
                 redx = el.data;
                 e = enext;
                 continue;
@@ -324,14 +391,14 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
             if (!have_vec)
             {
                 V3 d;
-                d.x = w.hit.x - k->pos[0];
-                d.y = w.hit.y - k->pos[1];
-                d.z = w.hit.z - k->pos[2];
+                d.x = w.hit.x - kp0;
+                d.y = w.hit.y - kp1;
+                d.z = w.hit.z - kp2;
                 w.cxyz = d;
                 if (ktrm != 0)
                 {
-                    V3 p = xform(k, ktrm, d);
-                    if (ktag < 0)
+                    V3 p = xform(kp, ktrm, d);
+                    if (karr)
                     {
                         w.cxyz = p;
                         redx = el.data;
@@ -342,31 +409,30 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
                 }
             }
             {
-                const V3 cv = k->shift ? w.cijk : w.cxyz;
-                const int ckind = k->srf_t[2];
+                const V3 cv = DF_SHIFT(kf) ? w.cijk : w.cxyz;
+                const int ckind = (int)DF_CKIND(kf);
                 float f4 = 0.0f, f5, f6, f1, f2, f3;
                 bool ok = true;
                 if (ckind == 1)
                 {
-                    const u32 kax = k->axes;
-                    f4 = fxor(vget(cv, ax_map(kax, 2)), ax_sgn(kax, 2));
+                    f4 = fxor(vget(cv, (int)DF_MAP(kf, 2)), DF_SGN(kf, 2));
                 }
                 else if (ckind == 2)
                 {
-                    f4 = cv.x; f1 = k->scj[0]; f1 = f1 + f1; f1 = f1 * f4;
-                    f4 = f4 * f4; f4 = f4 * k->sci[0]; f4 = f4 - f1;
-                    f5 = cv.y; f2 = k->scj[1]; f2 = f2 + f2; f2 = f2 * f5;
-                    f5 = f5 * f5; f5 = f5 * k->sci[1]; f5 = f5 - f2;
-                    f6 = cv.z; f3 = k->scj[2]; f3 = f3 + f3; f3 = f3 * f6;
-                    f6 = f6 * f6; f6 = f6 * k->sci[2]; f6 = f6 - f3;
-                    f4 = f4 - k->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                    f4 = cv.x; f1 = kp->scj[0]; f1 = f1 + f1; f1 = f1 * f4;
+                    f4 = f4 * f4; f4 = f4 * kp->sci[0]; f4 = f4 - f1;
+                    f5 = cv.y; f2 = kp->scj[1]; f2 = f2 + f2; f2 = f2 * f5;
+                    f5 = f5 * f5; f5 = f5 * kp->sci[1]; f5 = f5 - f2;
+                    f6 = cv.z; f3 = kp->scj[2]; f3 = f3 + f3; f3 = f3 * f6;
+                    f6 = f6 * f6; f6 = f6 * kp->sci[2]; f6 = f6 - f3;
+                    f4 = f4 - kp->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
                 }
                 else if (ckind == 3)
                 {
-                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * k->sci[0];
-                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * k->sci[1];
-                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * k->sci[2];
-                    f4 = f4 - k->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * kp->sci[0];
+                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * kp->sci[1];
+                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * kp->sci[2];
+                    f4 = f4 - kp->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
                 }
                 else
                 {
@@ -385,186 +451,169 @@ __device__ __forceinline__ bool clip(const DevScene &sc, SrfP s,
 }
 
 /* ------------------------------------------------------------------------ */
-/* OO_cyc for a group of lanes that share the list `head` (wave-uniform)     */
-/* tracer.cpp:1341-1592, 3955-4054, 4062-4136, 4216-4277, 4378-4842          */
+/* one list element for the lanes of a group (everything about the element   */
+/* and its surface is wave-uniform): tracer.cpp:1341-1592, 3955-4054,        */
+/* 4062-4136, 4216-4277, 4378-4842                                           */
 /* ------------------------------------------------------------------------ */
 
 template <bool SHADOW>
-__device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
+__device__ __forceinline__ void walk_element(const DevScene &sc, const int e, const qr_elem &el, const SV &s,
+                                             const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live)
 {
-    Walk w;
-    w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
-    w.hit = {0, 0, 0}; w.nxyz = {0, 0, 0}; w.nijk = {0, 0, 0};
-    w.cxyz = {0, 0, 0}; w.cijk = {0, 0, 0};
-    w.tbuf = r.tmax;
-    w.local_obj = QR_NULL;
-    w.resume = QR_NULL;
-    w.dmask = 0; w.amask = 0;
+    const int si = el.simd;
+    const u32 fl = s.p->flags;
+    const bool is_arr = DF_ARRAY(fl) != 0;
+    const int has_trm = (int)DF_TRM(fl);
+    const int sh = (int)DF_SHIFT(fl);
+    const bool on = live && w.resume == QR_NULL;
+    const bool same = si == r.osi;
 
-    bool live = true;
-    int e = head;
-
-    while (e != QR_NULL)
+    if (!__any(on))
     {
-        e = __builtin_amdgcn_readfirstlane(e);
-        const qr_elem el = ld_elem(c_elm(sc) + e);
-        const int si = el.simd;
-        SrfP s = c_srf(sc) + si;
-        const int tag = s->srf_t[3];
-        const int has_trm = s->has_trm;
-        const int sh = s->shift;
-        const bool on = live && w.resume == QR_NULL;
-        const bool same = si == r.osi;
+        /* every lane of the group is inside a bounding-volume skip (or done) */
+        if (w.resume == e) w.resume = QR_NULL;
+        return;
+    }
 
-        if (!__any(on))
+    if (on)
+    {
+        if (same)
         {
-            /* every lane of the group is inside a bounding-volume skip (or
-             * done): nothing to compute for this element */
-            if (w.resume == e) w.resume = QR_NULL;
-            if (SHADOW && !__any(live)) break;
-            e = el.next;
-            continue;
+            if (sh) w.dijk = r.ploc; else w.dxyz = r.ploc;
         }
-
-        if (on)
+        if (!is_arr && w.local_obj != QR_NULL)
         {
-            if (same)
+            if (!same)
             {
-                if (sh) w.dijk = r.ploc; else w.dxyz = r.ploc;
+                w.dijk.x = w.dxyz.x - s.p->pos[0];
+                w.dijk.y = w.dxyz.y - s.p->pos[1];
+                w.dijk.z = w.dxyz.z - s.p->pos[2];
             }
-            if (tag >= 0 && w.local_obj != QR_NULL)
-            {
-                if (!same)
-                {
-                    w.dijk.x = w.dxyz.x - s->pos[0];
-                    w.dijk.y = w.dxyz.y - s->pos[1];
-                    w.dijk.z = w.dxyz.z - s->pos[2];
-                }
-                if (e == w.local_obj) w.local_obj = QR_NULL;
-            }
-            else
-            {
-                bool do_ray = true;
-                if (!same)
-                {
-                    V3 d;
-                    d.x = r.org.x - s->pos[0];
-                    d.y = r.org.y - s->pos[1];
-                    d.z = r.org.z - s->pos[2];
-                    w.dxyz = d;
-                    if (has_trm == 0)
-                    {
-                        do_ray = false;
-                    }
-                    else
-                    {
-                        V3 p = xform(s, has_trm, d);
-                        if (tag < 0) { w.dxyz = p; w.local_obj = el.data; }
-                        else         { w.dijk = p; }
-                    }
-                }
-                if (do_ray) w.rijk = xform(s, has_trm, r.dir);
-            }
+            if (e == w.local_obj) w.local_obj = QR_NULL;
         }
-
-        if ((el.kind & 3) == 1)
+        else
         {
-            /* AR_ptr 3955-4054 */
-            if (on)
+            bool do_ray = true;
+            if (!same)
             {
-                const V3 ry = sh ? w.rijk : r.dir;
-                const V3 df = sh ? w.dijk : w.dxyz;
-                float x0, x1, x2, x3, x4, x5, x6, x7;
-                x1 = ry.x; x0 = s->sci[0] * x1; x5 = df.x; x7 = s->sci[0] * x5;
-                x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
-                x2 = ry.y; x0 = s->sci[1] * x2; x6 = df.y; x7 = s->sci[1] * x6;
-                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x2 = ry.z; x0 = s->sci[2] * x2; x6 = df.z; x7 = s->sci[2] * x6;
-                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x5 = x5 - s->sci[3];
-                x5 = x5 * x1;
-                x3 = x3 * x3;
-                x3 = x3 - x5;
-                if (!cle(0.0f, x3))
+                V3 d;
+                d.x = r.org.x - s.p->pos[0];
+                d.y = r.org.y - s.p->pos[1];
+                d.z = r.org.z - s.p->pos[2];
+                w.dxyz = d;
+                if (has_trm == 0)
                 {
-                    w.resume = el.data;
-                    if (w.resume == w.local_obj) w.local_obj = QR_NULL;
-                }
-            }
-            e = el.next;
-            continue;
-        }
-
-        const int solver = s->srf_t[0];
-        if (solver != 0)
-        {
-            /* up to two candidate roots per lane, in the lane's own order */
-            float ct0 = 0.0f, ct1 = 0.0f;
-            int   cs0 = 0, cs1 = 0;
-            bool  cm0 = false, cm1 = false;
-            int   ncand = 1;
-
-            if (solver == 1)
-            {
-                /* PL_ptr 4062-4136 */
-                const u32 axes = s->axes;
-                const int mk = ax_map(axes, 2);
-                const u32 sg = ax_sgn(axes, 2);
-                const V3 ry = sh ? w.rijk : r.dir;
-                const V3 df = sh ? w.dijk : w.dxyz;
-                float dk = fxor(vget(df, mk), sg);
-                const float rk = fxor(vget(ry, mk), sg);
-                dk = fxor(dk, s->smask);
-                cm0 = on && !same && cne(0.0f, rk);
-                ct0 = dk / rk;
-                cs0 = clt(rk, 0.0f) ? 0 : 1;
-            }
-            else
-            {
-                float a, b, c, d;
-                const V3 ry = sh ? w.rijk : r.dir;
-                const V3 df = sh ? w.dijk : w.dxyz;
-                if (solver == 2)
-                {
-                    /* QD_ptr 4378-4447 */
-                    float x0, x1, x2, x3, x4, x5, x6, x7;
-                    x1 = ry.x; x0 = s->sci[0] * x1; x5 = df.x; x7 = s->sci[0] * x5;
-                    x7 = x7 - s->scj[0]; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s->scj[0]; x5 = x5 * x7;
-                    x2 = ry.y; x0 = s->sci[1] * x2; x6 = df.y; x7 = s->sci[1] * x6;
-                    x7 = x7 - s->scj[1]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s->scj[1]; x6 = x6 * x7;
-                    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                    x2 = ry.z; x0 = s->sci[2] * x2; x6 = df.z; x7 = s->sci[2] * x6;
-                    x7 = x7 - s->scj[2]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s->scj[2]; x6 = x6 * x7;
-                    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                    x5 = x5 - s->sci[3];
-                    x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
-                    a = x1; b = x4; c = x6; d = x3;
+                    do_ray = false;
                 }
                 else
                 {
-                    /* TP_ptr 4216-4277 */
-                    const u32 axes = s->axes;
-                    const int mi = ax_map(axes, 0), mk = ax_map(axes, 2);
-                    float x0, x1, x2, x3, x4, x5, x6, x7;
-                    x1 = vget(ry, mi); x5 = vget(df, mi); x3 = sci_at(s,mi);
-                    x2 = vget(ry, mk); x6 = vget(df, mk); x4 = sci_at(s,mk);
-                    x0 = x5; x7 = x6;
-                    x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
-                    x5 = fabs_bits(x5);
-                    x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
-                    x4 = sci_at(s,mk);
-                    x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
-                    x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
-                    a = x1; b = x3; c = x0; d = x5;
+                    V3 p = xform(s.p, has_trm, d);
+                    if (is_arr) { w.dxyz = p; w.local_obj = el.data; }
+                    else        { w.dijk = p; }
                 }
+            }
+            if (do_ray) w.rijk = xform(s.p, has_trm, r.dir);
+        }
+    }
 
-                /* QD_rts 4449-4658 */
-                const u32 sm = s->smask;
-                const bool xmask = on && cle(0.0f, d);
+    if ((el.kind & 3) == 1)
+    {
+        /* AR_ptr 3955-4054 */
+        if (on)
+        {
+            const V3 ry = sh ? w.rijk : r.dir;
+            const V3 df = sh ? w.dijk : w.dxyz;
+            float x0, x1, x2, x3, x4, x5, x6, x7;
+            x1 = ry.x; x0 = s.p->sci[0] * x1; x5 = df.x; x7 = s.p->sci[0] * x5;
+            x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
+            x2 = ry.y; x0 = s.p->sci[1] * x2; x6 = df.y; x7 = s.p->sci[1] * x6;
+            x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+            x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+            x2 = ry.z; x0 = s.p->sci[2] * x2; x6 = df.z; x7 = s.p->sci[2] * x6;
+            x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+            x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+            x5 = x5 - s.p->sci[3];
+            x5 = x5 * x1;
+            x3 = x3 * x3;
+            x3 = x3 - x5;
+            if (!cle(0.0f, x3))
+            {
+                w.resume = el.data;
+                if (w.resume == w.local_obj) w.local_obj = QR_NULL;
+            }
+        }
+        if (w.resume == e) w.resume = QR_NULL;
+        return;
+    }
+
+    const int solver = (int)DF_SOLVER(fl);
+    if (solver != 0)
+    {
+        /* up to two candidate roots per lane, in the lane's own order */
+        float ct0 = 0.0f, ct1 = 0.0f;
+        int   cs0 = 0, cs1 = 0;
+        bool  cm0 = false, cm1 = false;
+        int   ncand = 1;
+        const V3 ry = sh ? w.rijk : r.dir;
+        const V3 df = sh ? w.dijk : w.dxyz;
+
+        if (solver == 1)
+        {
+            /* PL_ptr 4062-4136 */
+            const int mk = (int)DF_MAP(fl, 2);
+            const u32 sg = DF_SGN(fl, 2);
+            float dk = fxor(vget(df, mk), sg);
+            const float rk = fxor(vget(ry, mk), sg);
+            dk = fxor(dk, QR_SMASK);
+            cm0 = on && !same && cne(0.0f, rk);
+            ct0 = dk / rk;
+            cs0 = clt(rk, 0.0f) ? 0 : 1;
+        }
+        else
+        {
+            float a, b, c, d;
+            if (solver == 2)
+            {
+                /* QD_ptr 4378-4447 */
+                float x0, x1, x2, x3, x4, x5, x6, x7;
+                x1 = ry.x; x0 = s.p->sci[0] * x1; x5 = df.x; x7 = s.p->sci[0] * x5;
+                x7 = x7 - s.p->scj[0]; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.p->scj[0]; x5 = x5 * x7;
+                x2 = ry.y; x0 = s.p->sci[1] * x2; x6 = df.y; x7 = s.p->sci[1] * x6;
+                x7 = x7 - s.p->scj[1]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.p->scj[1]; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x2 = ry.z; x0 = s.p->sci[2] * x2; x6 = df.z; x7 = s.p->sci[2] * x6;
+                x7 = x7 - s.p->scj[2]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.p->scj[2]; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x5 = x5 - s.p->sci[3];
+                x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
+                a = x1; b = x4; c = x6; d = x3;
+            }
+            else
+            {
+                /* TP_ptr 4216-4277 */
+                const int mi = (int)DF_MAP(fl, 0), mk = (int)DF_MAP(fl, 2);
+                float x0, x1, x2, x3, x4, x5, x6, x7;
+                x1 = vget(ry, mi); x5 = vget(df, mi); x3 = sci_at(s, mi);
+                x2 = vget(ry, mk); x6 = vget(df, mk); x4 = sci_at(s, mk);
+                x0 = x5; x7 = x6;
+                x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
+                x5 = fabs_bits(x5);
+                x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
+                x4 = sci_at(s, mk);
+                x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
+                x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
+                a = x1; b = x3; c = x0; d = x5;
+            }
+
+            /* QD_rts 4449-4658 */
+            const u32 sm = QR_SMASK;
+            const bool xmask = on && cle(0.0f, d);
+            ncand = 0;
+            /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
+            if (__any(xmask))
+            {
                 b = fxor(b, sm);
-                const bool dm = xmask && clt(d, s->d_eps);
+                const bool dm = xmask && clt(d, s.p->d_eps);
                 w.dmask = dm ? 0xFFFFFFFFu : 0u;
 
                 const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
@@ -593,7 +642,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
                     tdf = fxor(tdf, w.amask);
                     const bool f = cle(0.0f, tdf);
                     tdf = f ? tdf : 0.0f;
-                    float eps = f ? s->t_eps : 0.0f;
+                    float eps = f ? s.p->t_eps : 0.0f;
                     eps = eps * t1;
                     eps = fabs_bits(eps);
                     tdf = tdf * -0.5f;
@@ -615,42 +664,116 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
                 if (inner_first) { ct0 = t2; cs0 = 1; cm0 = mi2; ct1 = t1; cs1 = 0; cm1 = mo; }
                 else             { ct0 = t1; cs0 = 0; cm0 = mo;  ct1 = t2; cs1 = 1; cm1 = mi2; }
             }
+        }
 
-            bool done = false;
+        bool done = false;
 #pragma nounroll
-            for (int p = 0; p < ncand; p++)
+        for (int p = 0; p < ncand; p++)
+        {
+            const float t = p == 0 ? ct0 : ct1;
+            const int side = p == 0 ? cs0 : cs1;
+            bool m = (p == 0 ? cm0 : cm1) && !done;
+            if (!__any(m)) continue;
+            m = clip(sc, s, r, w, t, side, m);
+            if (m)
             {
-                const float t = p == 0 ? ct0 : ct1;
-                const int side = p == 0 ? cs0 : cs1;
-                bool m = (p == 0 ? cm0 : cm1) && !done;
-                if (!__any(m)) continue;
-                m = clip(sc, s, r, w, t, side, m);
-                if (m)
+                done = true;
+                if (SHADOW)
                 {
-                    done = true;
-                    if (SHADOW)
-                    {
-                        /* CHECK_SHAD 549-589 */
-                        const int props = side ? s->props[1] : s->props[0];
-                        const bool no_shadow = (props & QR_PROP_LIGHT) ||
-                                               ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT));
-                        if (!no_shadow) { occluded = true; live = false; }
-                    }
-                    else
-                    {
-                        /* PAINT_FRAG 653-662: depth write; shading is deferred */
-                        w.tbuf = t;
-                        h.t = t; h.si = si; h.side = side;
-                        h.loc = sh ? w.nijk : w.nxyz;
-                    }
+                    /* CHECK_SHAD 549-589 */
+                    const int props = side ? s.p->props1 : s.p->props0;
+                    const bool no_shadow = (props & QR_PROP_LIGHT) ||
+                                           ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT));
+                    if (!no_shadow) { occluded = true; live = false; }
+                }
+                else
+                {
+                    /* PAINT_FRAG 653-662: depth write; shading is deferred */
+                    w.tbuf = t;
+                    h.t = t; h.si = si; h.side = side;
+                    h.loc = sh ? w.nijk : w.nxyz;
                 }
             }
         }
+    }
 
-        if (w.resume == e) w.resume = QR_NULL;
+    if (w.resume == e) w.resume = QR_NULL;
+}
+
+/*
+ * OO_cyc for a group of lanes that share the list `head` (wave-uniform, not
+ * NULL).  Software pipeline: iteration i computes on (el, s) while the hot
+ * record of i+1 (sn) and the cell of i+2 (el2) are being fetched.
+ */
+template <bool SHADOW>
+__device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
+{
+    Walk w;
+    w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
+    w.hit = {0, 0, 0}; w.nxyz = {0, 0, 0}; w.nijk = {0, 0, 0};
+    w.cxyz = {0, 0, 0}; w.cijk = {0, 0, 0};
+    w.tbuf = r.tmax;
+    w.local_obj = QR_NULL;
+    w.resume = QR_NULL;
+    w.dmask = 0; w.amask = 0;
+
+    bool live = true;
+    const ElmP E = c_elm(sc);
+    const SrfP D = c_srf(sc);
+
+    int e = __builtin_amdgcn_readfirstlane(head);
+#if QR_PIPE == 2
+    qr_elem el = ld_elem(E + e);
+    SV s = ld_hot(D + el.simd);
+    qr_elem el1 = el;                               /* cell of element i+1 */
+    if (el.next != QR_NULL) el1 = ld_elem(E + el.next);
+
+    for (;;)
+    {
+        const bool has_next = el.next != QR_NULL;
+        SV sn = s;
+        qr_elem el2 = el1;
+        if (has_next)
+        {
+            sn = ld_hot(D + el1.simd);              /* in flight during this element */
+            if (el1.next != QR_NULL) el2 = ld_elem(E + el1.next);
+        }
+
+        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
+
+        if (SHADOW && !__any(live)) break;
+        if (!has_next) break;
+        e = el.next;
+        el = el1; s = sn; el1 = el2;
+    }
+#elif QR_PIPE == 1
+    /* only the 16-byte list cell of the next element is prefetched */
+    qr_elem el = ld_elem(E + e);
+    for (;;)
+    {
+        const bool has_next = el.next != QR_NULL;
+        const SV s = ld_hot(D + el.simd);
+        qr_elem el1 = el;
+        if (has_next) el1 = ld_elem(E + el.next);
+
+        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
+
+        if (SHADOW && !__any(live)) break;
+        if (!has_next) break;
+        e = el.next;
+        el = el1;
+    }
+#else
+    while (e != QR_NULL)
+    {
+        e = __builtin_amdgcn_readfirstlane(e);
+        const qr_elem el = ld_elem(E + e);
+        const SV s = ld_hot(D + el.simd);
+        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
         if (SHADOW && !__any(live)) break;
         e = el.next;
     }
+#endif
 }
 
 /*
@@ -672,7 +795,7 @@ __device__ __forceinline__ void traverse(const DevScene &sc, bool active, const 
         pending &= ~__ballot(mine);
         if (mine)
         {
-            walk_list<SHADOW>(sc, __builtin_amdgcn_readfirstlane(head), r, h, occluded);
+            walk_list<SHADOW>(sc, head, r, h, occluded);
         }
     }
 }
@@ -714,7 +837,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
      * except the wave-wide shadow traversals in the light loop */
     const int si = act ? h.si : 0;
     const int side = h.side;
-    const qr_surface *__restrict__ s = &sc.srf[si];
+    const DSurf *__restrict__ s = &sc.srf[si];
+    const DShade *__restrict__ sd = &sc.shd[si];
     const qr_frame &fr = sc.fr;
 
     V3 nrm = {0, 0, 1};
@@ -733,12 +857,12 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         x5 = r.dir.y * t; hit.y = x5 + r.org.y;
         x6 = r.dir.z * t; hit.z = x6 + r.org.z;
 
-        props = side | s->props[side];
-        mi = s->mat[side];
-        const u32 axes = s->axes;
-        const u32 tside = side ? s->smask : 0u;
-        const int has_trm = s->has_trm;
-        const int nkind = s->srf_t[1];
+        props = side | (side ? s->props1 : s->props0);
+        mi = sd->mat[side];
+        const u32 fl = s->flags;
+        const u32 tside = side ? QR_SMASK : 0u;
+        const int has_trm = (int)DF_TRM(fl);
+        const int nkind = (int)DF_NKIND(fl);
         float tu = 0.0f, tv = 0.0f;
         V3 ln = {0, 0, 0};                          /* normal in surface space */
 
@@ -747,11 +871,11 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
             /* PL_mat 4139-4193 */
             if (props & QR_PROP_TEXTURE)
             {
-                tu = fxor(vget(h.loc, ax_map(axes, 0)), ax_sgn(axes, 0));
-                tv = fxor(vget(h.loc, ax_map(axes, 1)), ax_sgn(axes, 1));
+                tu = fxor(vget(h.loc, (int)DF_MAP(fl, 0)), DF_SGN(fl, 0));
+                tv = fxor(vget(h.loc, (int)DF_MAP(fl, 1)), DF_SGN(fl, 1));
             }
             x6 = fxor(1.0f, tside);
-            vset(ln, ax_map(axes, 2), fxor(x6, ax_sgn(axes, 2)));
+            vset(ln, (int)DF_MAP(fl, 2), fxor(x6, DF_SGN(fl, 2)));
         }
         else
         {
@@ -771,8 +895,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         if (has_trm != 0)
         {
             /* MT_nrm 2184-2263: transposed trnode matrix */
-            const qr_surface *__restrict__ tr = &sc.srf[s->trnode];
-            const int ttrm = tr->has_trm;
+            const DSurf *__restrict__ tr = &sc.srf[s->trnode];
+            const int ttrm = (int)DF_TRM(tr->flags);
             x1 = ln.x; x2 = ln.y; x3 = ln.z;
             x4 = tr->tci[0] * x1;
             x5 = tr->tcj[1] * x2;
@@ -826,7 +950,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
             col.x = tex.x * fr.amb[0];
             col.y = tex.y * fr.amb[1];
             col.z = tex.z * fr.amb[2];
-            le = s->lst[side * 2];
+            le = sd->lst[side * 2];
         }
     }
 
@@ -854,6 +978,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         sr.list = el.data; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
         Hit sh; bool occ;
         if (COUNT) { if (lm) cnt.shadow++; }
+        if (sc.dbg & 2) lm = false;
+        if (sc.dbg & 1) occ = false; else
         traverse<true>(sc, lm, sr, sh, occ);
         if (lm && !occ)
         {
@@ -1036,7 +1162,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
                 }
                 o.want_tr = m_trn;
                 o.tdir = nd;
-                o.lst_tr = s->lst[(1 - side) * 2 + 1];
+                o.lst_tr = sd->lst[(1 - side) * 2 + 1];
             }
         }
 
@@ -1109,7 +1235,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
                 c_rfl = m_rfl_c + x0;
             }
             o.want_rf = true;
-            o.lst_rf = s->lst[side * 2 + 1];
+            o.lst_rf = sd->lst[side * 2 + 1];
         }
         o.c_trn = c_trn;
         o.c_rfl = c_rfl;
@@ -1122,8 +1248,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
 
 __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 
-template <bool COUNT>
-__global__ __launch_bounds__(QR_BLOCK)
+template <bool COUNT, int WAVES>
+__global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                       unsigned long long *__restrict__ counters)
 {
@@ -1142,12 +1268,17 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     else if (fsaa == 1) { bw = 16; px = (wv & 1) * 8 + (pix & 7);  py = (wv >> 1) * 4 + (pix >> 3); }
     else                { bw = 8;  px = (wv & 1) * 4 + (pix & 3);  py = (wv >> 1) * 4 + (pix >> 2); }
 
-    const int group = sc.group_first + (int)blockIdx.y * sc.group_stride;
-    const int x = (int)blockIdx.x * bw + px;
+    /* blocks are scheduled in the host-computed order (tiles that can spawn
+     * deep recursion first, so that their long waves overlap the bulk) */
+    const u32 ord = sc.order[blockIdx.x];
+    const int group = (int)(ord >> 16);
+    const int x = (int)(ord & 0xFFFFu) * bw + px;
     const int y = group * 8 + py;
 
     bool inside = x < fr.frm_w && y < fr.frm_h && y >= sc.row_begin && y < sc.row_end;
+    if (group < sc.group_first || (group - sc.group_first) % sc.group_stride != 0) inside = false;
     if (inside && sc.thnum > 1) inside = (y % sc.thnum) == sc.index;
+    if (!__any(inside)) return;                 /* whole wave outside this launch's rows */
 
     Counters cnt = {0, 0, 0, 0};
 
@@ -1280,7 +1411,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
                         ray.org = {f.hit[0], f.hit[1], f.hit[2]};
                         ray.dir = {f.rdir[0], f.rdir[1], f.rdir[2]};
                         ray.tmin = 0.0f; ray.tmax = fr.t_max;
-                        ray.list = sc.srf[psi].lst[pside * 2 + 1];
+                        ray.list = sc.shd[psi].lst[pside * 2 + 1];
                         ray.osi = psi; ray.oflg = pside;
                         ray.ploc = {f.loc[0], f.loc[1], f.loc[2]};
                         mode = 0;
