@@ -9,17 +9,23 @@ starts.
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU (see DESIGN.md "Multi-GPU"): every step renders N frames; each frame's
-8-row tile rows are dealt to the N ranks in contiguous blocks (rotated per frame for
-balance), every rank renders its blocks of all N frames, then ONE RCCL all-to-all
-moves the blocks so that rank f ends the step holding the complete frame f.  Per-GPU
-work is constant in N (weak scaling); the exchange is overlapped with the next
-step's kernels on a second stream.
+Multi-GPU (quadray-engine_amd/sharding.py, DESIGN.md "Multi-GPU"): every step renders N
+frames; each frame's 8-row tile rows are dealt to the N ranks in contiguous blocks
+(rotated per frame for balance), every rank renders its blocks of all N frames, then
+ONE exchange over RCCL moves the blocks so that rank f ends the step holding the
+complete frame f.  Per-GPU work is constant in N (weak scaling); the exchange runs on
+its own stream and overlaps the next step's kernels.
+
+Rays are counted by the backend's counting kernel variant (not timed): primary +
+shadow + reflection + refraction rays actually traced ("useful" rays: the backend
+shades only the final hit of a list walk, the reference also shades overdrawn hits).
+The same count is used for the CPU baseline so that the two Mrays/s are comparable.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import gzip
+import importlib.util
 import json
 import os
 import subprocess
@@ -51,6 +57,24 @@ def load_blob(name):
         return gzip.decompress(f.read())
 
 
+def load_sharding():
+    spec = importlib.util.spec_from_file_location("qr_sharding", os.path.join(ROOT, "quadray-engine_amd", "sharding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); None if not measured."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
     """Time the CPU path on this box's host cores (rank 0, N=1 only): the unmodified reference
     (oracle/_ref/qr_ref, kind "reference") when its prebuilt binary travelled with the repo,
@@ -63,18 +87,20 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
             import tempfile
             tmp = tempfile.mkdtemp(prefix="qrbench_")
             os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
-            # calibrate with 3 frames, then fill the budget
+
             def run(n):
                 out = subprocess.run([ref] + ref_args + ["--threads", str(cores), "--bench", str(n)],
                                      cwd=tmp, capture_output=True, text=True, timeout=300)
                 line = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0].split()
-                return float(line[line.index("median_ms") + 1])
-            ms = run(3)
-            n = int(max(5, min(2000, frames_budget_s * 1000.0 / max(ms, 0.01))))
-            ms = run(n)
+                head = out.stdout.splitlines()[0]
+                return float(line[line.index("median_ms") + 1]), head
+            ms, _ = run(3)                      # calibrate, then fill the time budget
+            n = int(max(5, min(3000, frames_budget_s * 1000.0 / max(ms, 0.01))))
+            ms, head = run(n)
+            simd = head.split("simd ")[1].split()[0] if "simd " in head else "auto"
             return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="reference",
-                        sample=f"{n} frames of the same workload through rt_Scene::render (update phases included), "
-                               f"median {ms:.3f} ms/frame, auto-selected SIMD target")
+                        sample=f"{n} frames of the same workload through the unmodified reference's rt_Scene::render "
+                               f"(update phases included, SIMD target {simd}, {cores} threads), median {ms:.3f} ms/frame")
         except Exception as e:  # fall through to the port
             print(f"reference baseline failed: {e}", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -94,8 +120,8 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -104,13 +130,13 @@ def main():
     import torch.distributed as dist
     from qr_loader import load_package
     qr = load_package()
+    sharding = load_sharding()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -121,17 +147,14 @@ def main():
     scn = qr.Scene(blob, device=local_rank)
     W, H = scn.width, scn.height
     n_groups = (H + 7) // 8
+    N = world
 
     # deterministic ray count of one frame (counting kernel variant, not timed)
     _, rc = scn.render_count()
     rays_per_frame = rc.total()
     samples_per_frame = rc.primary
 
-    N = world
-    # block b (0..N-1) = tile rows [bounds[b], bounds[b+1])
-    bounds = [(n_groups * b) // N for b in range(N + 1)]
-    row_lo = [min(H, bounds[b] * 8) for b in range(N + 1)]
-
+    ex = sharding.FrameExchange(H, W, N, rank)
     compute = torch.cuda.Stream()
     comm = torch.cuda.Stream()
     frames = [[scn.new_frame() for _ in range(N)] for _ in range(2)]    # double-buffered render targets
@@ -144,17 +167,14 @@ def main():
         with torch.cuda.stream(compute):
             compute.wait_event(ev_comm[buf])            # the exchange that last read this buffer is done
             for f in range(N):
-                b = (rank + f) % N                      # rotate blocks over frames for balance
-                scn.set_rows(row_lo[b], row_lo[b + 1], 0, 1)
+                r0, r1 = ex.my_rows(f)
+                scn.set_rows(r0, r1, 0, 1)
                 scn.render(frames[buf][f], stream=compute)
             ev_render[buf].record(compute)
         if N > 1:
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_render[buf])
-                # rank r sends block (r+f)%N of frame f to rank f; receives block (s+rank)%N from rank s
-                send = [frames[buf][f][row_lo[(rank + f) % N]:row_lo[(rank + f) % N + 1]].reshape(-1) for f in range(N)]
-                recv = [finals[buf][row_lo[(s + rank) % N]:row_lo[(s + rank) % N + 1]].reshape(-1) for s in range(N)]
-                dist.all_to_all(recv, send)
+                ex.exchange(frames[buf], finals[buf])
                 ev_comm[buf].record(comm)
 
     for i in range(args.warmup):
@@ -176,7 +196,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # correctness gate inside the bench: the assembled frame must hash to the reference's
+    # correctness gate inside the bench: the assembled frame must equal a whole-frame render
     ok = True
     if N > 1:
         whole = scn.new_frame()
@@ -188,7 +208,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
-    # dominant-kernel duration, HIP events on the launch stream (full-frame launches)
+    # dominant-kernel duration: HIP events recorded on the launch stream around full-frame launches
     scn.set_rows(0, H, 0, 1)
     avg_ms, min_ms = scn.render_timed(frames[0][0], max(20, min(args.steps, 200)), stream=compute)
     torch.cuda.synchronize()
@@ -200,15 +220,17 @@ def main():
         bw = {0: 32, 1: 16, 2: 8}[scn.info.fsaa]
         n_wg = ((W + bw - 1) // bw) * n_groups
         # bytes_alg = 4*W*H (frame write) + n_workgroups * scene_bytes, scene_bytes = the
-        # surface + material + light records one workgroup needs (256 / 128 / 64 B records of qr_scene.h)
-        scene_bytes = scn.info.n_srf * 256 + scn.info.n_mat * 128 + scn.info.n_lgt * 64
+        # surface + material + light records one workgroup needs (128 B device surface records + 32 B shading
+        # records, 128 B materials, 64 B lights)
+        scene_bytes = scn.info.n_srf * (128 + 32) + scn.info.n_mat * 128 + scn.info.n_lgt * 64
         alg_bytes = 4 * W * H + n_wg * scene_bytes
-        roofline = dict(bound="hbm", achieved=alg_bytes / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(args.workload),
                         kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms,
                         algorithmic_bytes_per_launch=alg_bytes,
-                        note="path is scalar-per-ray fp32 VALU work; HBM fraction is small by construction "
-                             "(4 B/pixel out + one scene read per workgroup), see DESIGN.md")
+                        note="the path is scalar-per-ray fp32 VALU work: the HBM fraction is small by construction "
+                             "(4 B/pixel out + one scene read per workgroup), see DESIGN.md 'Roofline'")
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -216,7 +238,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
                        "frames_per_step": N, "rays_per_frame": rays_per_frame,
-                       "rays": rc.as_dict(), "parallelism": f"tile-row blocks x{N} + all-to-all" if N > 1 else "single GPU",
+                       "rays": rc.as_dict(),
+                       "parallelism": f"tile-row blocks x{N} + 1 exchange/step" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
                        "assembled_frame_matches": ok},
             "roofline": roofline,

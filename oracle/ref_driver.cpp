@@ -227,7 +227,7 @@ static void usage()
 int main(int argc, char **argv)
 {
     const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL;
-    int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0;
+    int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
     long time_ms = 0;
 
@@ -247,6 +247,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
         else if (!strcmp(argv[i], "--snapshot") && i + 1 < argc) snap_path = argv[++i];
         else if (!strcmp(argv[i], "--bench") && i + 1 < argc) bench = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gpu")) gpu = 1;
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else { usage(); return 2; }
     }
@@ -314,6 +315,41 @@ int main(int argc, char **argv)
             double sum = 0; for (double v : ms) sum += v;
             printf("bench frames %d min_ms %.3f median_ms %.3f mean_ms %.3f\n",
                    bench, ms[0], ms[ms.size() / 2], sum / ms.size());
+        }
+
+        if (gpu)
+        {
+            /* DROP-IN TEST: same engine, same scene object, but the backend namespace occupied by
+             * oracle/ref_shim.cpp -> qr_render0 -> HIP kernel.  The frame must equal the CPU SIMD frame. */
+            uint64_t cpu_hash = fnv1a64_frame(frame, w, h, row);
+            int got = pfm->set_simd(simd_init(1, 8, 1));
+            if (((got >> 8) & 0xFF) != 8 || (got & 0xFF) != 1)
+            {
+                fprintf(stderr, "shim target 128x1v8 not selectable (got %x); is this qr_ref_shim?\n", got);
+                return 4;
+            }
+            pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+            memset(frame, 0, (size_t)row * h * 4);
+            qr_shim_snapshot_path = NULL;
+            qr_shim_calls = 0;
+            sc->render(time_ms);
+            uint64_t gpu_hash = fnv1a64_frame(sc->get_frame(), w, h, sc->get_x_row());
+            printf("gpu_hash %016llx shim_calls %d %s\n", (unsigned long long)gpu_hash, qr_shim_calls,
+                   gpu_hash == cpu_hash ? "MATCH" : "MISMATCH");
+            if (gpu_hash != cpu_hash) rc = 6;
+            if (bench > 0)
+            {
+                std::vector<double> ms;
+                for (int i = 0; i < bench; i++)
+                {
+                    double t0 = now_ms();
+                    sc->render(time_ms);
+                    ms.push_back(now_ms() - t0);
+                }
+                std::sort(ms.begin(), ms.end());
+                printf("gpu_bench frames %d min_ms %.3f median_ms %.3f (engine update + flatten + upload + kernel + copy back)\n",
+                       bench, ms[0], ms[ms.size() / 2]);
+            }
         }
 
         if (snap_path != NULL)

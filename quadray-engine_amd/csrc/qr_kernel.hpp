@@ -113,6 +113,7 @@ struct DevScene
     int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
     const uint32_t    *__restrict__ order;  /* block schedule: bx | by << 16, heavy tiles first */
     int32_t n_blocks;
+    unsigned long long *stats;    /* QR_STATS builds only: walk statistics */
     int32_t dbg;                  /* timing experiments only (QR_DBG): 1 no shadow walks, 2 no lights */
 };
 
@@ -764,15 +765,30 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         el = el1;
     }
 #else
+#ifdef QR_STATS
+    unsigned long long st_iter = 0, st_lanes = 0;
+#endif
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
         const qr_elem el = ld_elem(E + e);
         const SV s = ld_hot(D + el.simd);
+#ifdef QR_STATS
+        st_iter++; st_lanes += __popcll(__ballot(live && w.resume == QR_NULL));
+#endif
         walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
         if (SHADOW && !__any(live)) break;
         e = el.next;
     }
+#ifdef QR_STATS
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        const int b = SHADOW ? 0 : (r.osi == QR_NULL ? 3 : 6);
+        atomicAdd(&sc.stats[b + 0], 1ull);
+        atomicAdd(&sc.stats[b + 1], st_iter);
+        atomicAdd(&sc.stats[b + 2], st_lanes);
+    }
+#endif
 #endif
 }
 
@@ -1309,6 +1325,12 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     }
 
     Frame stk[QR_MAX_DEPTH];
+#ifdef QR_STATS
+    unsigned long long tk0 = __builtin_amdgcn_s_memtime(), tk_trav = 0, tk_shade = 0, tk_rest = 0, tk1;
+#define QR_TICK(acc) do { tk1 = __builtin_amdgcn_s_memtime(); acc += tk1 - tk0; tk0 = tk1; } while (0)
+#else
+#define QR_TICK(acc) do { } while (0)
+#endif
     int sp = 0;
     int mode = inside ? 0 : 2;                  /* 0 trace, 1 return, 2 done */
     V3 ret = {0, 0, 0};
@@ -1323,13 +1345,16 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         if (__any(tr))
         {
             Hit h; bool occ;
+            QR_TICK(tk_rest);
             traverse<false>(sc, tr, ray, h, occ);
+            QR_TICK(tk_trav);
             const bool got = tr && h.si != QR_NULL;
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
             if (got && sp == 0) hit_id = (h.si << 1) | h.side;
 
             Shaded o;
             shade<COUNT>(sc, got, ray, h, o, cnt);
+            QR_TICK(tk_shade);
 
             if (got)
             {
@@ -1435,6 +1460,13 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         }
     }
 
+    QR_TICK(tk_rest);
+#ifdef QR_STATS
+    if (lane == 0)
+    {
+        atomicAdd(&sc.stats[9], tk_trav); atomicAdd(&sc.stats[10], tk_shade); atomicAdd(&sc.stats[11], tk_rest);
+    }
+#endif
     /* XX_end 5161-5343: clamp, FSAA reduce, gamma, pack */
     float cr = clamp1(ret.x), cg = clamp1(ret.y), cb = clamp1(ret.z);
     if (fsaa >= 1)

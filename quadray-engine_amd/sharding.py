@@ -1,0 +1,71 @@
+"""Multi-GPU decomposition of the frame (host-side plumbing, torch.distributed only).
+
+The reference shards work by scanline across threads (core/tracer/tracer.cpp:1144-1145,
+5385-5386) and culls by 8-row screen tiles (core/engine/engine.h:38-39).  Across GPUs we shard
+by contiguous blocks of 8-row TILE ROWS:
+
+  * a step renders `world` frames ("frames in flight": consecutive animation frames in
+    production, the same frozen snapshot in bench.py);
+  * frame f is cut into `world` blocks of tile rows; block b of frame f is rendered by rank
+    (b - f) mod world, i.e. rank r renders block (r + f) mod world of every frame, so each rank
+    touches every screen region once per step (sky/geometry imbalance cancels);
+  * ONE exchange per step (grouped point-to-point sends = an all-to-all over RCCL/xGMI, one
+    message per peer link) moves the blocks so that rank f ends the step owning the complete
+    frame f.  No reduction is needed: pixels are written exactly once.
+
+Per-GPU work is one frame's worth of rays per step whatever `world` is (weak scaling).
+With world == 1 nothing is exchanged.
+"""
+import torch
+import torch.distributed as dist
+
+TILE_H = 8
+
+
+def block_rows(height, world):
+    """Row boundaries of the `world` tile-row blocks: block b = rows [lo[b], lo[b+1])."""
+    groups = (height + TILE_H - 1) // TILE_H
+    return [min(height, ((groups * b) // world) * TILE_H) for b in range(world + 1)]
+
+
+def block_of(rank, frame, world):
+    """Block of frame `frame` that rank `rank` renders."""
+    return (rank + frame) % world
+
+
+class FrameExchange:
+    """Assembles, on rank f, the complete frame f from the blocks every rank rendered."""
+
+    def __init__(self, height, width, world, rank):
+        self.h, self.w, self.world, self.rank = height, width, world, rank
+        self.lo = block_rows(height, world)
+
+    def my_rows(self, frame):
+        b = block_of(self.rank, frame, self.world)
+        return self.lo[b], self.lo[b + 1]
+
+    def exchange(self, frames, final, group=None):
+        """frames: list of `world` [h,w] tensors (rank's blocks rendered in place);
+        final: [h,w] tensor receiving frame `rank`.  Returns after the transfers completed
+        (on the current stream for NCCL)."""
+        world, rank, lo = self.world, self.rank, self.lo
+        if world == 1:
+            final.copy_(frames[0])
+            return
+        ops, keep = [], []
+        for peer in range(world):
+            sb = block_of(rank, peer, world)            # my block of frame `peer` goes to rank `peer`
+            rb = block_of(peer, rank, world)            # peer's block of frame `rank` comes to me
+            src = frames[peer][lo[sb]:lo[sb + 1]]
+            dst = final[lo[rb]:lo[rb + 1]]
+            if peer == rank:
+                dst.copy_(src)
+                continue
+            if src.numel():
+                ops.append(dist.P2POp(dist.isend, src, peer, group))
+            if dst.numel():
+                ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+            keep += [src, dst]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()

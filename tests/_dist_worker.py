@@ -1,0 +1,55 @@
+"""Worker for tests/test_distributed_cpu.py: one rank of the tile-row sharding + exchange on gloo.
+The oracle stands in for the GPU renderer (tests may use it); the sharding/exchange code under test is
+the product's quadray-engine_amd/sharding.py."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import qr_oracle
+    from conftest import load_blob
+    spec = importlib.util.spec_from_file_location("qr_sharding", os.path.join(ROOT, "quadray-engine_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    blob = load_blob(sys.argv[1])
+    info = qr_oracle.info(blob)
+    h, w = info["h"], info["w"]
+    ex = sharding.FrameExchange(h, w, world, rank)
+    # frame f = the snapshot at recursion depth f (distinct images per frame)
+    frames = []
+    for f in range(world):
+        r0, r1 = ex.my_rows(f)
+        part, _, _ = qr_oracle.render(blob, depth=f, threads=1, rows=(r0, r1))
+        frames.append(torch.from_numpy(part.astype(np.int64)).to(torch.int32))
+    final = torch.zeros((h, w), dtype=torch.int32)
+    ex.exchange(frames, final)
+    whole, _, _ = qr_oracle.render(blob, depth=rank, threads=1)
+    ok = bool((final.numpy().view(np.uint32) == whole).all())
+    # every row of every frame is rendered by exactly one rank
+    cover = torch.zeros((world, h), dtype=torch.int32)
+    for f in range(world):
+        r0, r1 = ex.my_rows(f)
+        cover[f, r0:r1] += 1
+    dist.all_reduce(cover)
+    ok = ok and bool((cover == 1).all())
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -92,3 +92,24 @@ def test_gpu_is_deterministic(qr):
     _, a, _ = _gpu_frame(qr, blob)
     _, b, _ = _gpu_frame(qr, blob)
     assert (a == b).all()
+
+
+def test_gpu_drop_in_through_reference_engine():
+    """The UNMODIFIED reference engine (prebuilt oracle/_ref/qr_ref_shim), linked with the shim TU in
+    place of tracer_128v8.cpp, renders once with its own CPU SIMD backend and once through
+    qr_render0 -> HIP; the driver compares the two frames."""
+    import os
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/qr_ref_shim was not built (needs /root/reference at build time)")
+    tmp = tempfile.mkdtemp(prefix="qrdrop_")
+    os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
+    for args in (["--scene", "demo01", "-w", "640", "-h", "480"],
+                 ["--scene", "demo02", "-w", "320", "-h", "240", "--gamma", "--fresnel", "--fsaa", "4", "-t", "3000"],
+                 ["--scene", "test13", "-w", "200", "-h", "150", "--opts", "none"]):
+        out = subprocess.run([exe] + args + ["--gpu"], cwd=tmp, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
