@@ -238,64 +238,100 @@ struct Hit
     V3 loc;                 /* local (possibly conic-adjusted) hit, ctx_NEW   */
 };
 
+/* what a lane carries from one list element to the next (kept minimal: every
+ * loop-carried value costs a copy per element) */
 struct Walk
 {
     V3 dxyz, dijk;          /* ctx_DFF_X..Z / I..K                            */
     V3 rijk;                /* ctx_RAY_I..K                                   */
-    V3 hit;                 /* ctx_HIT                                        */
-    V3 nxyz, nijk;          /* ctx_NEW_X..Z / I..K                            */
-    V3 cxyz, cijk;          /* ctx_NRM_* used as clip temporaries             */
-    float tbuf;
-    int local_obj;          /* ctx_LOCAL(OBJ)                                 */
+    float tbuf;             /* ctx_T_BUF                                      */
+    int local_obj;          /* ctx_LOCAL(OBJ): trnode's last element          */
     int resume;             /* element at which a bounding-volume skip ends   */
-    u32 dmask, amask;       /* ctx_DMASK / ctx_AMASK (as 0/~0 and sign bits)  */
 };
 
+/* the hot 80 bytes of a DSurf, fetched with five 16-byte scalar loads issued
+ * back to back (one wait) */
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+struct Hot
+{
+    float pos0, pos1, pos2; u32 flags;
+    float sci0, sci1, sci2, sci3;
+    float scj0, scj1, scj2; int clip;
+    float min0, min1, min2, d_eps;
+    float max0, max1, max2, t_eps;
+};
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ Hot ld_hot5(SrfP p)
+{
+    const QR_CONST u32x4 *q = (const QR_CONST u32x4 *)p;
+    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    Hot h;
+    h.pos0 = u2f(a.x); h.pos1 = u2f(a.y); h.pos2 = u2f(a.z); h.flags = a.w;
+    h.sci0 = u2f(b.x); h.sci1 = u2f(b.y); h.sci2 = u2f(b.z); h.sci3 = u2f(b.w);
+    h.scj0 = u2f(c.x); h.scj1 = u2f(c.y); h.scj2 = u2f(c.z); h.clip = (int)c.w;
+    h.min0 = u2f(d.x); h.min1 = u2f(d.y); h.min2 = u2f(d.z); h.d_eps = u2f(d.w);
+    h.max0 = u2f(e.x); h.max1 = u2f(e.y); h.max2 = u2f(e.z); h.t_eps = u2f(e.w);
+    return h;
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ float hsci(const Hot &s, int i) { return i == 0 ? s.sci0 : i == 1 ? s.sci1 : s.sci2; }
+
 /* ------------------------------------------------------------------------ */
-/* CC_clp, tracer.cpp:1597-2160                                              */
-/* `s` and the clipper list are wave-uniform                                 */
+/* CC_clp, tracer.cpp:1597-2160.  `s`, `P` and the clipper list are          */
+/* wave-uniform; every temporary is local to the call.  `loc` returns the    */
+/* local hit (ctx_NEW_* of the surface's space).                             */
 /* ------------------------------------------------------------------------ */
 
-__device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
-                                     const Ray &r, Walk &w, float t, int side, bool m)
+__device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
+                                     const Ray &r, const Walk &w, const V3 &ry, const V3 &df,
+                                     bool dmask, u32 amask, float t, int side, bool m, V3 &loc)
 {
-    const u32 fl = s.p->flags;
+    const u32 fl = s.flags;
     const int has_trm = (int)DF_TRM(fl);
-    const int sh = (int)DF_SHIFT(fl);
     float x4, x5, x6;
+    V3 hit;
 
     m = m && cgt(w.tbuf, t);
     m = m && clt(r.tmin, t);
 
-    x4 = r.dir.x * t; x4 = x4 + r.org.x; w.hit.x = x4;
-    x5 = r.dir.y * t; x5 = x5 + r.org.y; w.hit.y = x5;
-    x6 = r.dir.z * t; x6 = x6 + r.org.z; w.hit.z = x6;
+    x4 = r.dir.x * t; x4 = x4 + r.org.x; hit.x = x4;
+    x5 = r.dir.y * t; x5 = x5 + r.org.y; hit.y = x5;
+    x6 = r.dir.z * t; x6 = x6 + r.org.z; hit.z = x6;
 
+    V3 nijk = {0.0f, 0.0f, 0.0f};       /* ctx_NEW_I..K, only defined when has_trm != 0 */
     if (has_trm != 0)
     {
-        x4 = w.rijk.x * t; x4 = x4 + w.dijk.x; w.nijk.x = x4;
-        x5 = w.rijk.y * t; x5 = x5 + w.dijk.y; w.nijk.y = x5;
-        x6 = w.rijk.z * t; x6 = x6 + w.dijk.z; w.nijk.z = x6;
+        x4 = w.rijk.x * t; x4 = x4 + w.dijk.x;
+        x5 = w.rijk.y * t; x5 = x5 + w.dijk.y;
+        x6 = w.rijk.z * t; x6 = x6 + w.dijk.z;
+        nijk.x = x4; nijk.y = x5; nijk.z = x6;
     }
     else
     {
-        x4 = x4 - s.p->pos[0]; w.nxyz.x = x4;
-        x5 = x5 - s.p->pos[1]; w.nxyz.y = x5;
-        x6 = x6 - s.p->pos[2]; w.nxyz.z = x6;
+        x4 = x4 - s.pos0;
+        x5 = x5 - s.pos1;
+        x6 = x6 - s.pos2;
     }
+    /* the local hit the surface's own solvers/material see: NEW[shift] */
+    const int sh = (int)DF_SHIFT(fl);
+    V3 nw;
+    if ((sh != 0) == (has_trm != 0)) { nw.x = x4; nw.y = x5; nw.z = x6; }
+    else if (sh) { nw = nijk; }                     /* shift without transform: stale IJK (never built by the engine) */
+    else { nw.x = hit.x - s.pos0; nw.y = hit.y - s.pos1; nw.z = hit.z - s.pos2; }
 
     /* conic singularity solver, 1706-1856 */
     const int conic = (int)DF_CONIC(fl);
     if (conic != 0)
     {
         const int mi = (int)DF_MAP(fl, 0), mj = (int)DF_MAP(fl, 1), mk = (int)DF_MAP(fl, 2);
-        V3 nw = sh ? w.nijk : w.nxyz;
-        V3 df = sh ? w.dijk : w.dxyz;
         float x0, x1, x2, x3;
         x1 = vget(nw, mi); x1 = x1 * x1; x0 = x1;
         if (conic != 2) { x2 = vget(nw, mj); x2 = x2 * x2; x0 = x0 + x2; }
         x3 = vget(nw, mk); x3 = x3 * x3; x0 = x0 + x3;
-        bool hm = clt(x0, s.p->t_eps) && (w.dmask != 0);
+        const bool hm = clt(x0, s.t_eps) && dmask;
         if (hm)
         {
             const u32 sm = QR_SMASK;
@@ -303,54 +339,56 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
             float r4;
             x2 = 0.0f;
             x1 = u2f((f2u(vget(df, mi)) & sm) ^ f2u(one));
-            x3 = sci_at(s, mi);
+            x3 = hsci(s, mi);
             r4 = one;
             if (conic != 2)
             {
                 x2 = u2f((f2u(vget(df, mj)) & sm) ^ f2u(one));
-                x3 = x3 + sci_at(s, mj);
+                x3 = x3 + hsci(s, mj);
                 r4 = r4 + one;
             }
-            x3 = x3 / sci_at(s, mk);
+            x3 = x3 / hsci(s, mk);
             x3 = fxor(x3, sm);
             float y6 = x3;
             x3 = __builtin_sqrtf(x3);
             y6 = y6 + r4;
             r4 = rsq(y6);
-            r4 = r4 * s.p->t_eps;
+            r4 = r4 * s.t_eps;
             x1 = x1 * r4; x2 = x2 * r4; x3 = x3 * r4;
 
             const u32 tside = side ? sm : 0u;
             x3 = fxor(x3, f2u(vget(df, mk)) & sm);
-            x3 = fxor(x3, (tside & w.amask) ^ w.amask);
-            const u32 u5 = (tside | w.amask) ^ w.amask;
+            x3 = fxor(x3, (tside & amask) ^ amask);
+            const u32 u5 = (tside | amask) ^ amask;
             x1 = fxor(x1, u5);
             x2 = fxor(x2, u5);
 
             vset(nw, mi, x1);
             if (conic != 2) vset(nw, mj, x2);
             vset(nw, mk, x3);
-            if (sh) w.nijk = nw; else w.nxyz = nw;
+            if (sh) nijk = nw;
             x4 = nw.x; x5 = nw.y; x6 = nw.z;
         }
     }
+    loc = nw;
 
     /* axis min/max, 1874-1927 */
     const u32 mm = DF_MINMAX(fl);
-    if (mm & 0x01) m = m && cle(s.p->min[0], x4);
-    if (mm & 0x08) m = m && cge(s.p->max[0], x4);
-    if (mm & 0x02) m = m && cle(s.p->min[1], x5);
-    if (mm & 0x10) m = m && cge(s.p->max[1], x5);
-    if (mm & 0x04) m = m && cle(s.p->min[2], x6);
-    if (mm & 0x20) m = m && cge(s.p->max[2], x6);
+    if (mm & 0x01) m = m && cle(s.min0, x4);
+    if (mm & 0x08) m = m && cge(s.max0, x4);
+    if (mm & 0x02) m = m && cle(s.min1, x5);
+    if (mm & 0x10) m = m && cge(s.max1, x5);
+    if (mm & 0x04) m = m && cle(s.min2, x6);
+    if (mm & 0x20) m = m && cge(s.max2, x6);
 
     /* custom clipping, 1931-2151 */
-    int e = s.p->clip;
+    int e = s.clip;
     if (e != QR_NULL && __any(m))
     {
         int redx = QR_NULL;
-        const int local_lst = s.p->trnode;
+        const int local_lst = P->trnode;
         bool c_acc = false;
+        V3 cxyz = {0.0f, 0.0f, 0.0f}, cijk = {0.0f, 0.0f, 0.0f};   /* ctx_NRM_* as clip temporaries */
         while (e != QR_NULL)
         {
             e = __builtin_amdgcn_readfirstlane(e);
@@ -364,27 +402,27 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
                 continue;
             }
             SrfP kp = c_srf(sc) + el.simd;
-            const u32 kf = kp->flags;
+            const Hot k = ld_hot5(kp);
+            const u32 kf = k.flags;
             const int ktrm = (int)DF_TRM(kf);
             const bool karr = DF_ARRAY(kf) != 0;
-            const float kp0 = kp->pos[0], kp1 = kp->pos[1], kp2 = kp->pos[2];
             bool have_vec = false;
             if (!karr)
             {
                 if (redx != QR_NULL)
                 {
-                    w.cijk.x = w.cxyz.x - kp0;
-                    w.cijk.y = w.cxyz.y - kp1;
-                    w.cijk.z = w.cxyz.z - kp2;
+                    cijk.x = cxyz.x - k.pos0;
+                    cijk.y = cxyz.y - k.pos1;
+                    cijk.z = cxyz.z - k.pos2;
                     if (e == redx) redx = QR_NULL;
                     have_vec = true;
                 }
             }
             else if (el.simd == local_lst)
             {
-                w.cxyz.x = w.nijk.x + s.p->pos[0];
-                w.cxyz.y = w.nijk.y + s.p->pos[1];
-                w.cxyz.z = w.nijk.z + s.p->pos[2];
+                cxyz.x = nijk.x + s.pos0;
+                cxyz.y = nijk.y + s.pos1;
+                cxyz.z = nijk.z + s.pos2;
                 redx = el.data;
                 e = enext;
                 continue;
@@ -392,25 +430,25 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
             if (!have_vec)
             {
                 V3 d;
-                d.x = w.hit.x - kp0;
-                d.y = w.hit.y - kp1;
-                d.z = w.hit.z - kp2;
-                w.cxyz = d;
+                d.x = hit.x - k.pos0;
+                d.y = hit.y - k.pos1;
+                d.z = hit.z - k.pos2;
+                cxyz = d;
                 if (ktrm != 0)
                 {
                     V3 p = xform(kp, ktrm, d);
                     if (karr)
                     {
-                        w.cxyz = p;
+                        cxyz = p;
                         redx = el.data;
                         e = enext;
                         continue;
                     }
-                    w.cijk = p;
+                    cijk = p;
                 }
             }
             {
-                const V3 cv = DF_SHIFT(kf) ? w.cijk : w.cxyz;
+                const V3 cv = DF_SHIFT(kf) ? cijk : cxyz;
                 const int ckind = (int)DF_CKIND(kf);
                 float f4 = 0.0f, f5, f6, f1, f2, f3;
                 bool ok = true;
@@ -420,20 +458,20 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
                 }
                 else if (ckind == 2)
                 {
-                    f4 = cv.x; f1 = kp->scj[0]; f1 = f1 + f1; f1 = f1 * f4;
-                    f4 = f4 * f4; f4 = f4 * kp->sci[0]; f4 = f4 - f1;
-                    f5 = cv.y; f2 = kp->scj[1]; f2 = f2 + f2; f2 = f2 * f5;
-                    f5 = f5 * f5; f5 = f5 * kp->sci[1]; f5 = f5 - f2;
-                    f6 = cv.z; f3 = kp->scj[2]; f3 = f3 + f3; f3 = f3 * f6;
-                    f6 = f6 * f6; f6 = f6 * kp->sci[2]; f6 = f6 - f3;
-                    f4 = f4 - kp->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                    f4 = cv.x; f1 = k.scj0; f1 = f1 + f1; f1 = f1 * f4;
+                    f4 = f4 * f4; f4 = f4 * k.sci0; f4 = f4 - f1;
+                    f5 = cv.y; f2 = k.scj1; f2 = f2 + f2; f2 = f2 * f5;
+                    f5 = f5 * f5; f5 = f5 * k.sci1; f5 = f5 - f2;
+                    f6 = cv.z; f3 = k.scj2; f3 = f3 + f3; f3 = f3 * f6;
+                    f6 = f6 * f6; f6 = f6 * k.sci2; f6 = f6 - f3;
+                    f4 = f4 - k.sci3; f4 = f4 + f5; f4 = f4 + f6;
                 }
                 else if (ckind == 3)
                 {
-                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * kp->sci[0];
-                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * kp->sci[1];
-                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * kp->sci[2];
-                    f4 = f4 - kp->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
+                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * k.sci0;
+                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * k.sci1;
+                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * k.sci2;
+                    f4 = f4 - k.sci3; f4 = f4 + f5; f4 = f4 + f6;
                 }
                 else
                 {
@@ -458,241 +496,236 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const SV &s,
 /* ------------------------------------------------------------------------ */
 
 template <bool SHADOW>
-__device__ __forceinline__ void walk_element(const DevScene &sc, const int e, const qr_elem &el, const SV &s,
+__device__ __forceinline__ void walk_element(const DevScene &sc, const int e, const qr_elem &el, SrfP P,
                                              const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live)
 {
-    const int si = el.simd;
-    const u32 fl = s.p->flags;
-    const bool is_arr = DF_ARRAY(fl) != 0;
-    const int has_trm = (int)DF_TRM(fl);
-    const int sh = (int)DF_SHIFT(fl);
     const bool on = live && w.resume == QR_NULL;
-    const bool same = si == r.osi;
 
-    if (!__any(on))
+    if (__any(on))
     {
-        /* every lane of the group is inside a bounding-volume skip (or done) */
-        if (w.resume == e) w.resume = QR_NULL;
-        return;
-    }
+        const Hot s = ld_hot5(P);
+        const int si = el.simd;
+        const u32 fl = s.flags;
+        const bool is_arr = DF_ARRAY(fl) != 0;
+        const int has_trm = (int)DF_TRM(fl);
+        const int sh = (int)DF_SHIFT(fl);
 
-    if (on)
-    {
-        if (same)
-        {
-            if (sh) w.dijk = r.ploc; else w.dxyz = r.ploc;
-        }
-        if (!is_arr && w.local_obj != QR_NULL)
-        {
-            if (!same)
-            {
-                w.dijk.x = w.dxyz.x - s.p->pos[0];
-                w.dijk.y = w.dxyz.y - s.p->pos[1];
-                w.dijk.z = w.dxyz.z - s.p->pos[2];
-            }
-            if (e == w.local_obj) w.local_obj = QR_NULL;
-        }
-        else
-        {
-            bool do_ray = true;
-            if (!same)
-            {
-                V3 d;
-                d.x = r.org.x - s.p->pos[0];
-                d.y = r.org.y - s.p->pos[1];
-                d.z = r.org.z - s.p->pos[2];
-                w.dxyz = d;
-                if (has_trm == 0)
-                {
-                    do_ray = false;
-                }
-                else
-                {
-                    V3 p = xform(s.p, has_trm, d);
-                    if (is_arr) { w.dxyz = p; w.local_obj = el.data; }
-                    else        { w.dijk = p; }
-                }
-            }
-            if (do_ray) w.rijk = xform(s.p, has_trm, r.dir);
-        }
-    }
-
-    if ((el.kind & 3) == 1)
-    {
-        /* AR_ptr 3955-4054 */
         if (on)
         {
-            const V3 ry = sh ? w.rijk : r.dir;
-            const V3 df = sh ? w.dijk : w.dxyz;
-            float x0, x1, x2, x3, x4, x5, x6, x7;
-            x1 = ry.x; x0 = s.p->sci[0] * x1; x5 = df.x; x7 = s.p->sci[0] * x5;
-            x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
-            x2 = ry.y; x0 = s.p->sci[1] * x2; x6 = df.y; x7 = s.p->sci[1] * x6;
-            x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-            x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-            x2 = ry.z; x0 = s.p->sci[2] * x2; x6 = df.z; x7 = s.p->sci[2] * x6;
-            x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-            x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-            x5 = x5 - s.p->sci[3];
-            x5 = x5 * x1;
-            x3 = x3 * x3;
-            x3 = x3 - x5;
-            if (!cle(0.0f, x3))
+            const bool same = si == r.osi;
+
+            /* ---- diff / ray in the surface's space, 1352-1556 ---- */
+            if (same)
             {
-                w.resume = el.data;
-                if (w.resume == w.local_obj) w.local_obj = QR_NULL;
+                if (sh) w.dijk = r.ploc; else w.dxyz = r.ploc;
             }
-        }
-        if (w.resume == e) w.resume = QR_NULL;
-        return;
-    }
-
-    const int solver = (int)DF_SOLVER(fl);
-    if (solver != 0)
-    {
-        /* up to two candidate roots per lane, in the lane's own order */
-        float ct0 = 0.0f, ct1 = 0.0f;
-        int   cs0 = 0, cs1 = 0;
-        bool  cm0 = false, cm1 = false;
-        int   ncand = 1;
-        const V3 ry = sh ? w.rijk : r.dir;
-        const V3 df = sh ? w.dijk : w.dxyz;
-
-        if (solver == 1)
-        {
-            /* PL_ptr 4062-4136 */
-            const int mk = (int)DF_MAP(fl, 2);
-            const u32 sg = DF_SGN(fl, 2);
-            float dk = fxor(vget(df, mk), sg);
-            const float rk = fxor(vget(ry, mk), sg);
-            dk = fxor(dk, QR_SMASK);
-            cm0 = on && !same && cne(0.0f, rk);
-            ct0 = dk / rk;
-            cs0 = clt(rk, 0.0f) ? 0 : 1;
-        }
-        else
-        {
-            float a, b, c, d;
-            if (solver == 2)
+            if (!is_arr && w.local_obj != QR_NULL)
             {
-                /* QD_ptr 4378-4447 */
-                float x0, x1, x2, x3, x4, x5, x6, x7;
-                x1 = ry.x; x0 = s.p->sci[0] * x1; x5 = df.x; x7 = s.p->sci[0] * x5;
-                x7 = x7 - s.p->scj[0]; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.p->scj[0]; x5 = x5 * x7;
-                x2 = ry.y; x0 = s.p->sci[1] * x2; x6 = df.y; x7 = s.p->sci[1] * x6;
-                x7 = x7 - s.p->scj[1]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.p->scj[1]; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x2 = ry.z; x0 = s.p->sci[2] * x2; x6 = df.z; x7 = s.p->sci[2] * x6;
-                x7 = x7 - s.p->scj[2]; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.p->scj[2]; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x5 = x5 - s.p->sci[3];
-                x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
-                a = x1; b = x4; c = x6; d = x3;
+                if (!same)
+                {
+                    w.dijk.x = w.dxyz.x - s.pos0;
+                    w.dijk.y = w.dxyz.y - s.pos1;
+                    w.dijk.z = w.dxyz.z - s.pos2;
+                }
+                if (e == w.local_obj) w.local_obj = QR_NULL;
             }
             else
             {
-                /* TP_ptr 4216-4277 */
-                const int mi = (int)DF_MAP(fl, 0), mk = (int)DF_MAP(fl, 2);
+                bool do_ray = true;
+                if (!same)
+                {
+                    V3 d;
+                    d.x = r.org.x - s.pos0;
+                    d.y = r.org.y - s.pos1;
+                    d.z = r.org.z - s.pos2;
+                    w.dxyz = d;
+                    if (has_trm == 0)
+                    {
+                        do_ray = false;
+                    }
+                    else
+                    {
+                        V3 p = xform(P, has_trm, d);
+                        if (is_arr) { w.dxyz = p; w.local_obj = el.data; }
+                        else        { w.dijk = p; }
+                    }
+                }
+                if (do_ray) w.rijk = xform(P, has_trm, r.dir);
+            }
+
+            const V3 ry = sh ? w.rijk : r.dir;
+            const V3 df = sh ? w.dijk : w.dxyz;
+
+            if ((el.kind & 3) == 1)
+            {
+                /* AR_ptr 3955-4054 */
                 float x0, x1, x2, x3, x4, x5, x6, x7;
-                x1 = vget(ry, mi); x5 = vget(df, mi); x3 = sci_at(s, mi);
-                x2 = vget(ry, mk); x6 = vget(df, mk); x4 = sci_at(s, mk);
-                x0 = x5; x7 = x6;
-                x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
-                x5 = fabs_bits(x5);
-                x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
-                x4 = sci_at(s, mk);
-                x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
-                x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
-                a = x1; b = x3; c = x0; d = x5;
+                x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
+                x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
+                x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
+                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
+                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x5 = x5 - s.sci3;
+                x5 = x5 * x1;
+                x3 = x3 * x3;
+                x3 = x3 - x5;
+                if (!cle(0.0f, x3))
+                {
+                    w.resume = el.data;
+                    if (w.resume == w.local_obj) w.local_obj = QR_NULL;
+                }
             }
-
-            /* QD_rts 4449-4658 */
-            const u32 sm = QR_SMASK;
-            const bool xmask = on && cle(0.0f, d);
-            ncand = 0;
-            /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
-            if (__any(xmask))
+            else
             {
-                b = fxor(b, sm);
-                const bool dm = xmask && clt(d, s.p->d_eps);
-                w.dmask = dm ? 0xFFFFFFFFu : 0u;
+                const int solver = (int)DF_SOLVER(fl);
+                /* up to two candidate roots per lane, in the lane's own order */
+                float ct0 = 0.0f, ct1 = 0.0f;
+                int   cs0 = 0, cs1 = 0;
+                bool  cm0 = false, cm1 = false;
+                int   ncand = 0;
+                bool  dmask = false;
+                u32   amask = 0;
 
-                const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
-                const float bd = b + sd;
-                const bool m_pos = cle(0.0f, sd);
-                const bool m_neg = cgt(0.0f, sd);
-                const float t2n = u2f((m_neg ? f2u(c) : 0u)  | (m_pos ? f2u(bd) : 0u));
-                const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(c) : 0u));
-                float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
-                float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
-                a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
-
-                w.amask = sm & f2u(a);
-                if (dm)
+                if (solver == 1)
                 {
-                    if (ceq(t1n, 0.0f)) t1d = 1.0f;
-                    if (ceq(t2n, 0.0f)) t2d = 1.0f;
+                    /* PL_ptr 4062-4136 */
+                    const int mk = (int)DF_MAP(fl, 2);
+                    const u32 sg = DF_SGN(fl, 2);
+                    float dk = fxor(vget(df, mk), sg);
+                    const float rk = fxor(vget(ry, mk), sg);
+                    dk = fxor(dk, QR_SMASK);
+                    cm0 = !same && cne(0.0f, rk);
+                    ct0 = dk / rk;
+                    cs0 = clt(rk, 0.0f) ? 0 : 1;
+                    ncand = 1;
                 }
-                float t1 = t1n / t1d;
-                float t2 = t2n / t2d;
-                const bool t1msk = cne(t1d, 0.0f);
-                const bool t2msk = cne(t2d, 0.0f);
-                if (dm)
+                else if (solver != 0)
                 {
-                    float tdf = t1 - t2;
-                    tdf = fxor(tdf, w.amask);
-                    const bool f = cle(0.0f, tdf);
-                    tdf = f ? tdf : 0.0f;
-                    float eps = f ? s.p->t_eps : 0.0f;
-                    eps = eps * t1;
-                    eps = fabs_bits(eps);
-                    tdf = tdf * -0.5f;
-                    tdf = tdf - eps;
-                    tdf = fxor(tdf, w.amask);
-                    tdf = (t1msk && t2msk) ? tdf : 0.0f;
-                    t1 = t1 + tdf;
-                    t2 = t2 - tdf;
+                    float a, b, c, d;
+                    if (solver == 2)
+                    {
+                        /* QD_ptr 4378-4447 */
+                        float x0, x1, x2, x3, x4, x5, x6, x7;
+                        x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
+                        x7 = x7 - s.scj0; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.scj0; x5 = x5 * x7;
+                        x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
+                        x7 = x7 - s.scj1; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj1; x6 = x6 * x7;
+                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                        x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
+                        x7 = x7 - s.scj2; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj2; x6 = x6 * x7;
+                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                        x5 = x5 - s.sci3;
+                        x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
+                        a = x1; b = x4; c = x6; d = x3;
+                    }
+                    else
+                    {
+                        /* TP_ptr 4216-4277 */
+                        const int mi = (int)DF_MAP(fl, 0), mk = (int)DF_MAP(fl, 2);
+                        float x0, x1, x2, x3, x4, x5, x6, x7;
+                        x1 = vget(ry, mi); x5 = vget(df, mi); x3 = hsci(s, mi);
+                        x2 = vget(ry, mk); x6 = vget(df, mk); x4 = hsci(s, mk);
+                        x0 = x5; x7 = x6;
+                        x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
+                        x5 = fabs_bits(x5);
+                        x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
+                        x4 = hsci(s, mk);
+                        x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
+                        x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
+                        a = x1; b = x3; c = x0; d = x5;
+                    }
+
+                    /* QD_rts 4449-4658 */
+                    const u32 sm = QR_SMASK;
+                    const bool xmask = cle(0.0f, d);
+                    /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
+                    if (__any(xmask))
+                    {
+                        b = fxor(b, sm);
+                        dmask = xmask && clt(d, s.d_eps);
+
+                        const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
+                        const float bd = b + sd;
+                        const bool m_pos = cle(0.0f, sd);
+                        const bool m_neg = cgt(0.0f, sd);
+                        const float t2n = u2f((m_neg ? f2u(c) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                        const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(c) : 0u));
+                        float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
+                        float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                        a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
+
+                        amask = sm & f2u(a);
+                        if (dmask)
+                        {
+                            if (ceq(t1n, 0.0f)) t1d = 1.0f;
+                            if (ceq(t2n, 0.0f)) t2d = 1.0f;
+                        }
+                        float t1 = t1n / t1d;
+                        float t2 = t2n / t2d;
+                        const bool t1msk = cne(t1d, 0.0f);
+                        const bool t2msk = cne(t2d, 0.0f);
+                        if (dmask)
+                        {
+                            float tdf = t1 - t2;
+                            tdf = fxor(tdf, amask);
+                            const bool f = cle(0.0f, tdf);
+                            tdf = f ? tdf : 0.0f;
+                            float eps = f ? s.t_eps : 0.0f;
+                            eps = eps * t1;
+                            eps = fabs_bits(eps);
+                            tdf = tdf * -0.5f;
+                            tdf = tdf - eps;
+                            tdf = fxor(tdf, amask);
+                            tdf = (t1msk && t2msk) ? tdf : 0.0f;
+                            t1 = t1 + tdf;
+                            t2 = t2 - tdf;
+                        }
+
+                        const bool inner_first = xmask && cgt(0.0f, a);
+                        /* CHECK_SIDE 531-540 */
+                        const int f3 = r.oflg & (FLAG_SIDE | FLAG_PASS_THRU);
+                        const bool skip_outer = same && (f3 == 1 || f3 == 2);
+                        const bool skip_inner = same && (f3 == 0 || f3 == 3);
+                        const bool mo = xmask && t1msk && !skip_outer;
+                        const bool mi2 = xmask && t2msk && !skip_inner;
+                        ncand = 2;
+                        if (inner_first) { ct0 = t2; cs0 = 1; cm0 = mi2; ct1 = t1; cs1 = 0; cm1 = mo; }
+                        else             { ct0 = t1; cs0 = 0; cm0 = mo;  ct1 = t2; cs1 = 1; cm1 = mi2; }
+                    }
                 }
 
-                const bool inner_first = xmask && cgt(0.0f, a);
-                /* CHECK_SIDE 531-540 */
-                const int f3 = r.oflg & (FLAG_SIDE | FLAG_PASS_THRU);
-                const bool skip_outer = same && (f3 == 1 || f3 == 2);
-                const bool skip_inner = same && (f3 == 0 || f3 == 3);
-                const bool mo = xmask && t1msk && !skip_outer;
-                const bool mi2 = xmask && t2msk && !skip_inner;
-                ncand = 2;
-                if (inner_first) { ct0 = t2; cs0 = 1; cm0 = mi2; ct1 = t1; cs1 = 0; cm1 = mo; }
-                else             { ct0 = t1; cs0 = 0; cm0 = mo;  ct1 = t2; cs1 = 1; cm1 = mi2; }
-            }
-        }
-
-        bool done = false;
+                bool done = false;
 #pragma nounroll
-        for (int p = 0; p < ncand; p++)
-        {
-            const float t = p == 0 ? ct0 : ct1;
-            const int side = p == 0 ? cs0 : cs1;
-            bool m = (p == 0 ? cm0 : cm1) && !done;
-            if (!__any(m)) continue;
-            m = clip(sc, s, r, w, t, side, m);
-            if (m)
-            {
-                done = true;
-                if (SHADOW)
+                for (int p = 0; p < ncand; p++)
                 {
-                    /* CHECK_SHAD 549-589 */
-                    const int props = side ? s.p->props1 : s.p->props0;
-                    const bool no_shadow = (props & QR_PROP_LIGHT) ||
-                                           ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT));
-                    if (!no_shadow) { occluded = true; live = false; }
-                }
-                else
-                {
-                    /* PAINT_FRAG 653-662: depth write; shading is deferred */
-                    w.tbuf = t;
-                    h.t = t; h.si = si; h.side = side;
-                    h.loc = sh ? w.nijk : w.nxyz;
+                    const float t = p == 0 ? ct0 : ct1;
+                    const int side = p == 0 ? cs0 : cs1;
+                    bool m = (p == 0 ? cm0 : cm1) && !done;
+                    if (!__any(m)) continue;
+                    V3 loc;
+                    m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc);
+                    if (m)
+                    {
+                        done = true;
+                        if (SHADOW)
+                        {
+                            /* CHECK_SHAD 549-589 */
+                            const int props = side ? P->props1 : P->props0;
+                            const bool no_shadow = (props & QR_PROP_LIGHT) ||
+                                                   ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT));
+                            if (!no_shadow) { occluded = true; live = false; }
+                        }
+                        else
+                        {
+                            /* PAINT_FRAG 653-662: depth write; shading is deferred */
+                            w.tbuf = t;
+                            h.t = t; h.si = si; h.side = side;
+                            h.loc = loc;
+                        }
+                    }
                 }
             }
         }
@@ -702,84 +735,55 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
 }
 
 /*
- * OO_cyc for a group of lanes that share the list `head` (wave-uniform, not
- * NULL).  Software pipeline: iteration i computes on (el, s) while the hot
- * record of i+1 (sn) and the cell of i+2 (el2) are being fetched.
+ * OO_cyc for a group of lanes that share the list `head` (wave-uniform, not NULL).
  */
 template <bool SHADOW>
 __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ray &r, Hit &h, bool &occluded)
 {
     Walk w;
     w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
-    w.hit = {0, 0, 0}; w.nxyz = {0, 0, 0}; w.nijk = {0, 0, 0};
-    w.cxyz = {0, 0, 0}; w.cijk = {0, 0, 0};
     w.tbuf = r.tmax;
     w.local_obj = QR_NULL;
     w.resume = QR_NULL;
-    w.dmask = 0; w.amask = 0;
 
     bool live = true;
     const ElmP E = c_elm(sc);
     const SrfP D = c_srf(sc);
 
     int e = __builtin_amdgcn_readfirstlane(head);
-#if QR_PIPE == 2
-    qr_elem el = ld_elem(E + e);
-    SV s = ld_hot(D + el.simd);
-    qr_elem el1 = el;                               /* cell of element i+1 */
-    if (el.next != QR_NULL) el1 = ld_elem(E + el.next);
-
-    for (;;)
-    {
-        const bool has_next = el.next != QR_NULL;
-        SV sn = s;
-        qr_elem el2 = el1;
-        if (has_next)
-        {
-            sn = ld_hot(D + el1.simd);              /* in flight during this element */
-            if (el1.next != QR_NULL) el2 = ld_elem(E + el1.next);
-        }
-
-        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
-
-        if (SHADOW && !__any(live)) break;
-        if (!has_next) break;
-        e = el.next;
-        el = el1; s = sn; el1 = el2;
-    }
-#elif QR_PIPE == 1
-    /* only the 16-byte list cell of the next element is prefetched */
+#ifdef QR_STATS
+    unsigned long long st_iter = 0, st_lanes = 0;
+#endif
+#if QR_PIPE == 1
+    /* the 16-byte list cell of the next element is fetched while this one is intersected */
     qr_elem el = ld_elem(E + e);
     for (;;)
     {
         const bool has_next = el.next != QR_NULL;
-        const SV s = ld_hot(D + el.simd);
         qr_elem el1 = el;
         if (has_next) el1 = ld_elem(E + el.next);
-
-        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
-
+#ifdef QR_STATS
+        st_iter++; st_lanes += __popcll(__ballot(live && w.resume == QR_NULL));
+#endif
+        walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live);
         if (SHADOW && !__any(live)) break;
         if (!has_next) break;
         e = el.next;
         el = el1;
     }
 #else
-#ifdef QR_STATS
-    unsigned long long st_iter = 0, st_lanes = 0;
-#endif
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
         const qr_elem el = ld_elem(E + e);
-        const SV s = ld_hot(D + el.simd);
 #ifdef QR_STATS
         st_iter++; st_lanes += __popcll(__ballot(live && w.resume == QR_NULL));
 #endif
-        walk_element<SHADOW>(sc, e, el, s, r, w, h, occluded, live);
+        walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live);
         if (SHADOW && !__any(live)) break;
         e = el.next;
     }
+#endif
 #ifdef QR_STATS
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
     {
@@ -789,8 +793,8 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         atomicAdd(&sc.stats[b + 2], st_lanes);
     }
 #endif
-#endif
 }
+
 
 /*
  * Wave-wide traversal: lanes with `active` walk their lists; lanes that share
