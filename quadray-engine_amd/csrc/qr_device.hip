@@ -28,7 +28,8 @@ struct qr_device_scene
     int device;
     void *d_blob;               /* one allocation holding every array      */
     uint64_t blob_bytes;
-    DevScene sc;                /* device pointers + frame parameters       */
+    DevScene sc;                /* device pointers + launch parameters      */
+    qr_frame fr;                /* host copy of the frame parameters        */
     qr_header hdr;
     unsigned long long *d_counters;
     hipEvent_t ev0, ev1;
@@ -154,33 +155,43 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
     size_t o_til = pad16(o_elm + (size_t)(n_elm + 1) * sizeof(qr_elem));
     size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
-    /* block schedule */
-    const int bwid = fr.fsaa == 0 ? 32 : fr.fsaa == 1 ? 16 : 8;
-    const int nbx = (fr.frm_w + bwid - 1) / bwid, nby = (fr.frm_h + 7) / 8;
+    /* wave schedule: one entry per wave footprint (8x8 / 8x4 / 4x4 pixels) */
+    const int fw = fr.fsaa == 2 ? 4 : 8, fh = fr.fsaa == 0 ? 8 : 4;
+    const int nbx = (fr.frm_w + fw - 1) / fw, nby = (fr.frm_h + fh - 1) / fh;
     if (nbx > 0xFFFF || nby > 0xFFFF) return qr_fail(QR_ERR_ARG, "frame too large");
     std::vector<uint32_t> order;
     {
-        std::vector<uint32_t> heavy, light;
-        for (int by = 0; by < nby; by++)
-            for (int bx = 0; bx < nbx; bx++)
+        /* heavy = the footprint's tile list holds a reflective or non-opaque surface */
+        std::vector<uint8_t> tile_heavy((size_t)fr.tls_row * fr.tls_col, 0);
+        for (size_t t = 0; t < tile_heavy.size(); t++)
+            for (int e = v.tiles[t]; e != QR_NULL && !tile_heavy[t]; e = v.elm[e].next)
             {
-                const int tx = (bx * bwid) / fr.tile_w, ty = (by * 8) / fr.tile_h;
-                bool hv = false;
-                if (tx < fr.tls_row && ty < fr.tls_col)
-                    for (int e = v.tiles[ty * fr.tls_row + tx]; e != QR_NULL && !hv; e = v.elm[e].next)
-                    {
-                        const qr_surface &q = v.srf[v.elm[e].simd];
-                        if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
-                        for (int k = 0; k < 2; k++)
-                            if ((q.props[k] & QR_PROP_REFLECT) || !(q.props[k] & QR_PROP_OPAQUE)) hv = true;
-                    }
-                (hv ? heavy : light).push_back((uint32_t)bx | ((uint32_t)by << 16));
+                const qr_surface &q = v.srf[v.elm[e].simd];
+                if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+                for (int k = 0; k < 2; k++)
+                    if ((q.props[k] & QR_PROP_REFLECT) || !(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] = 1;
             }
+        std::vector<uint32_t> heavy, light;
+        /* enumerate footprints tile by tile (32x8 pixel groups) to keep neighbours together */
+        const int gx = 32 / fw, gy = 8 / fh;
+        for (int ty = 0; ty * gy < nby; ty++)
+            for (int tx = 0; tx * gx < nbx; tx++)
+                for (int j = 0; j < gy; j++)
+                    for (int i = 0; i < gx; i++)
+                    {
+                        const int bx = tx * gx + i, by = ty * gy + j;
+                        if (bx >= nbx || by >= nby) continue;
+                        const int px = bx * fw, py = by * fh;
+                        const int tlx = px / fr.tile_w, tly = py / fr.tile_h;
+                        const bool hv = tlx < fr.tls_row && tly < fr.tls_col && tile_heavy[(size_t)tly * fr.tls_row + tlx];
+                        (hv ? heavy : light).push_back((uint32_t)bx | ((uint32_t)by << 16));
+                    }
         order = heavy;
         order.insert(order.end(), light.begin(), light.end());
     }
     size_t o_ord = pad16(o_tex + (size_t)(n_tex + 1) * 4);
-    size_t total = pad16(o_ord + order.size() * 4 + 16);
+    size_t o_frm = pad16(o_ord + order.size() * 4 + 16);
+    size_t total = pad16(o_frm + sizeof(qr_frame));
 
     std::vector<uint8_t> host(total, 0);
     /* repack qr_surface (256 B, snapshot layout) into the device records:
@@ -226,6 +237,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
     memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
     memcpy(host.data() + o_ord, order.data(), order.size() * 4);
+    memcpy(host.data() + o_frm, &fr, sizeof(qr_frame));
 
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -248,7 +260,8 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     s->sc.order = (const uint32_t *)(d + o_ord);
     s->sc.n_blocks = (int32_t)order.size();
     s->sc.stats = s->d_counters + 4;
-    s->sc.fr = fr;
+    s->sc.frp = (const qr_frame *)(d + o_frm);
+    s->fr = fr;
     s->sc.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
     s->sc.row_begin = 0; s->sc.row_end = fr.frm_h;
     s->sc.index = fr.index; s->sc.thnum = fr.thnum > 0 ? fr.thnum : 1;
@@ -275,11 +288,11 @@ extern "C" int qr_scene_get_info(const qr_device_scene *s, qr_scene_info *info)
 {
     if (s == nullptr || info == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     memset(info, 0, sizeof(*info));
-    info->frm_w = s->sc.fr.frm_w; info->frm_h = s->sc.fr.frm_h;
-    info->fsaa = s->sc.fr.fsaa; info->depth = s->sc.depth;
+    info->frm_w = s->fr.frm_w; info->frm_h = s->fr.frm_h;
+    info->fsaa = s->fr.fsaa; info->depth = s->sc.depth;
     info->n_srf = (int32_t)s->hdr.n_srf; info->n_mat = (int32_t)s->hdr.n_mat; info->n_lgt = (int32_t)s->hdr.n_lgt;
     info->n_elm = (int32_t)s->hdr.n_elm; info->n_tiles = (int32_t)s->hdr.n_tiles; info->n_texels = (int32_t)s->hdr.n_texels;
-    info->tile_w = s->sc.fr.tile_w; info->tile_h = s->sc.fr.tile_h;
+    info->tile_w = s->fr.tile_w; info->tile_h = s->fr.tile_h;
     info->device_bytes = s->blob_bytes;
     return QR_OK;
 }
@@ -295,7 +308,7 @@ extern "C" int qr_scene_set_depth(qr_device_scene *s, int depth)
 extern "C" int qr_scene_set_rows(qr_device_scene *s, int row_begin, int row_end, int index, int thnum)
 {
     if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
-    const int h = s->sc.fr.frm_h;
+    const int h = s->fr.frm_h;
     if (row_begin < 0 || row_end > h || row_begin > row_end) return qr_fail(QR_ERR_ARG, "bad row range");
     if (thnum <= 0 || index < 0 || index >= thnum) return qr_fail(QR_ERR_ARG, "bad index/thnum");
     s->sc.row_begin = row_begin; s->sc.row_end = row_end;
@@ -309,9 +322,9 @@ extern "C" int qr_scene_set_rows(qr_device_scene *s, int row_begin, int row_end,
 extern "C" int qr_scene_set_tile_rows(qr_device_scene *s, int first, int stride)
 {
     if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
-    const int total = (s->sc.fr.frm_h + 7) / 8;
+    const int total = (s->fr.frm_h + 7) / 8;
     if (stride <= 0 || first < 0) return qr_fail(QR_ERR_ARG, "bad tile-row selection");
-    s->sc.row_begin = 0; s->sc.row_end = s->sc.fr.frm_h;
+    s->sc.row_begin = 0; s->sc.row_end = s->fr.frm_h;
     s->sc.index = 0; s->sc.thnum = 1;
     s->sc.group_first = first; s->sc.group_stride = stride;
     s->sc.n_groups = first < total ? (total - first + stride - 1) / stride : 0;
@@ -321,10 +334,10 @@ extern "C" int qr_scene_set_tile_rows(qr_device_scene *s, int first, int stride)
 template <bool COUNT>
 static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, hipStream_t st)
 {
-    const int fsaa = s->sc.fr.fsaa;
+    const int fsaa = s->fr.fsaa;
     const int bw = fsaa == 0 ? 32 : fsaa == 1 ? 16 : 8;
     (void)bw;
-    dim3 grid(s->sc.n_blocks, 1, 1);
+    dim3 grid((s->sc.n_blocks + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64), 1, 1);
     if (grid.x == 0 || s->sc.n_groups == 0) return hipSuccess;
     /* register budget variant (waves per SIMD); QR_WAVES is a tuning knob for experiments */
     static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
@@ -403,7 +416,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
 extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_pixels)
 {
     if (s == nullptr || frame_host == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
-    const int w = s->sc.fr.frm_w, h = s->sc.fr.frm_h;
+    const int w = s->fr.frm_w, h = s->fr.frm_h;
     HIP_TRY(hipSetDevice(s->device));
     void *d_frame = nullptr;
     HIP_TRY(hipMalloc(&d_frame, (size_t)w * h * 4));

@@ -45,7 +45,9 @@
 #include <stdint.h>
 #include "qr_scene.h"
 
+#ifndef QR_BLOCK
 #define QR_BLOCK 256
+#endif
 #ifndef QR_MAX_DEPTH
 #define QR_MAX_DEPTH 10           /* RT_STACK_DEPTH, tracer.h:46 */
 #endif
@@ -53,7 +55,7 @@
 #define QR_PIPE 0                 /* list-walk prefetch depth: 0 none, 1 next cell, 2 next cell + next record */
 #endif
 #ifndef QR_MIN_WAVES_PER_SIMD
-#define QR_MIN_WAVES_PER_SIMD 3   /* __launch_bounds__ 2nd argument: waves per SIMD */
+#define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
 #endif
 
 typedef uint32_t u32;
@@ -106,7 +108,7 @@ struct DevScene
     const qr_elem     *__restrict__ elm;
     const int32_t     *__restrict__ tiles;
     const uint32_t    *__restrict__ texels;
-    qr_frame fr;
+    const qr_frame    *__restrict__ frp;    /* frame/camera parameters (device memory, scalar-loaded on demand) */
     int32_t depth;
     int32_t row_begin, row_end;   /* rows rendered by this launch            */
     int32_t index, thnum;         /* reference row interleave                */
@@ -171,6 +173,8 @@ typedef const QR_CONST qr_elem *ElmP;
 #pragma clang diagnostic ignored "-Wold-style-cast"
 __device__ __forceinline__ SrfP c_srf(const DevScene &sc) { return (SrfP)sc.srf; }
 __device__ __forceinline__ ElmP c_elm(const DevScene &sc) { return (ElmP)sc.elm; }
+typedef const QR_CONST qr_frame *FrmP;
+__device__ __forceinline__ FrmP c_frm(const DevScene &sc) { return (FrmP)sc.frp; }
 #pragma clang diagnostic pop
 
 __device__ __forceinline__ qr_elem ld_elem(ElmP p)
@@ -277,7 +281,14 @@ __device__ __forceinline__ Hot ld_hot5(SrfP p)
 }
 #pragma clang diagnostic pop
 
-__device__ __forceinline__ float hsci(const Hot &s, int i) { return i == 0 ? s.sci0 : i == 1 ? s.sci1 : s.sci2; }
+/* sci[axis] for a wave-uniform axis: scalar bit-select (a ternary chain over the
+ * struct members is turned into a scratch lookup table by the compiler, which
+ * costs a scratch store per list element) */
+__device__ __forceinline__ float hsci(const Hot &s, int i)
+{
+    const u32 m0 = i == 0 ? 0xFFFFFFFFu : 0u, m1 = i == 1 ? 0xFFFFFFFFu : 0u, m2 = i == 2 ? 0xFFFFFFFFu : 0u;
+    return u2f((f2u(s.sci0) & m0) | (f2u(s.sci1) & m1) | (f2u(s.sci2) & m2));
+}
 
 /* ------------------------------------------------------------------------ */
 /* CC_clp, tracer.cpp:1597-2160.  `s`, `P` and the clipper list are          */
@@ -580,7 +591,7 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
             }
             else
             {
-                const int solver = (int)DF_SOLVER(fl);
+                const int solver = (SHADOW && (sc.dbg & 32)) ? 0 : (int)DF_SOLVER(fl);
                 /* up to two candidate roots per lane, in the lane's own order */
                 float ct0 = 0.0f, ct1 = 0.0f;
                 int   cs0 = 0, cs1 = 0;
@@ -704,7 +715,7 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
                     const float t = p == 0 ? ct0 : ct1;
                     const int side = p == 0 ? cs0 : cs1;
                     bool m = (p == 0 ? cm0 : cm1) && !done;
-                    if (!__any(m)) continue;
+                    if (!__any(m) || (SHADOW && (sc.dbg & 16))) continue;
                     V3 loc;
                     m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc);
                     if (m)
@@ -859,7 +870,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
     const int side = h.side;
     const DSurf *__restrict__ s = &sc.srf[si];
     const DShade *__restrict__ sd = &sc.shd[si];
-    const qr_frame &fr = sc.fr;
+    const FrmP fr = c_frm(sc);
 
     V3 nrm = {0, 0, 1};
     V3 tex = {0, 0, 0};
@@ -967,9 +978,9 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         }
         else
         {
-            col.x = tex.x * fr.amb[0];
-            col.y = tex.y * fr.amb[1];
-            col.z = tex.z * fr.amb[2];
+            col.x = tex.x * fr->amb[0];
+            col.y = tex.y * fr->amb[1];
+            col.z = tex.z * fr->amb[2];
             le = sd->lst[side * 2];
         }
     }
@@ -1273,8 +1284,8 @@ __global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                       unsigned long long *__restrict__ counters)
 {
-    const qr_frame &fr = sc.fr;
-    const int fsaa = fr.fsaa;
+    const FrmP fr = c_frm(sc);
+    const int fsaa = fr->fsaa;
     const int ns = 1 << fsaa;
     const int tid = threadIdx.x;
     const int wv = tid >> 6;
@@ -1282,20 +1293,19 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     const int pix = lane >> fsaa;               /* pixel index inside the wave */
     const int k = lane & (ns - 1);              /* sample index inside the pixel */
 
-    /* wave footprint: 8x8 pixels (no AA), 8x4 (2x), 4x4 (4x); block = 32x8 / 16x8 / 8x8 */
-    int bw, px, py;
-    if (fsaa == 0)      { bw = 32; px = wv * 8 + (pix & 7);        py = pix >> 3; }
-    else if (fsaa == 1) { bw = 16; px = (wv & 1) * 8 + (pix & 7);  py = (wv >> 1) * 4 + (pix >> 3); }
-    else                { bw = 8;  px = (wv & 1) * 4 + (pix & 3);  py = (wv >> 1) * 4 + (pix >> 2); }
+    /* wave footprint: 8x8 pixels (no AA), 8x4 (2x), 4x4 (4x).  Every WAVE takes one entry of
+     * the host-computed schedule (footprints that can spawn deep recursion first, so that their
+     * long waves overlap the bulk instead of forming a tail); consecutive entries are
+     * neighbouring footprints, so the waves of a workgroup still share tile lists. */
+    const int fw = fsaa == 2 ? 4 : 8, fh = fsaa == 0 ? 8 : 4;
+    const int gw = (int)blockIdx.x * (QR_BLOCK / 64) + wv;
+    if (gw >= sc.n_blocks) return;
+    const u32 ord = sc.order[gw];
+    const int x = (int)(ord & 0xFFFFu) * fw + (fsaa == 2 ? (pix & 3) : (pix & 7));
+    const int y = (int)(ord >> 16) * fh + (fsaa == 2 ? (pix >> 2) : (pix >> 3));
+    const int group = y >> 3;
 
-    /* blocks are scheduled in the host-computed order (tiles that can spawn
-     * deep recursion first, so that their long waves overlap the bulk) */
-    const u32 ord = sc.order[blockIdx.x];
-    const int group = (int)(ord >> 16);
-    const int x = (int)(ord & 0xFFFFu) * bw + px;
-    const int y = group * 8 + py;
-
-    bool inside = x < fr.frm_w && y < fr.frm_h && y >= sc.row_begin && y < sc.row_end;
+    bool inside = x < fr->frm_w && y < fr->frm_h && y >= sc.row_begin && y < sc.row_end;
     if (group < sc.group_first || (group - sc.group_first) % sc.group_stride != 0) inside = false;
     if (inside && sc.thnum > 1) inside = (y % sc.thnum) == sc.index;
     if (!__any(inside)) return;                 /* whole wave outside this launch's rows */
@@ -1308,22 +1318,22 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         int ai = 0;
         if (fsaa == 1) ai = (x & 1) * 2 + k;
         if (fsaa == 2) ai = k;
-        float hs = (float)x + fr.hor_a[ai]; hs = hs + 0.0f;
-        float vs = (float)y + fr.ver_a[ai]; vs = vs + 0.0f;
-        float x1 = fr.hor[0] * hs, x2 = fr.hor[1] * hs, x3 = fr.hor[2] * hs;
-        float x4 = fr.ver[0] * vs, x5 = fr.ver[1] * vs, x6 = fr.ver[2] * vs;
+        float hs = (float)x + fr->hor_a[ai]; hs = hs + 0.0f;
+        float vs = (float)y + fr->ver_a[ai]; vs = vs + 0.0f;
+        float x1 = fr->hor[0] * hs, x2 = fr->hor[1] * hs, x3 = fr->hor[2] * hs;
+        float x4 = fr->ver[0] * vs, x5 = fr->ver[1] * vs, x6 = fr->ver[2] * vs;
         x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
-        ray.dir.x = x1 + fr.dir[0];
-        ray.dir.y = x2 + fr.dir[1];
-        ray.dir.z = x3 + fr.dir[2];
-        ray.org.x = fr.org[0]; ray.org.y = fr.org[1]; ray.org.z = fr.org[2];
-        ray.tmin = fr.t_min; ray.tmax = fr.t_max;
+        ray.dir.x = x1 + fr->dir[0];
+        ray.dir.y = x2 + fr->dir[1];
+        ray.dir.z = x3 + fr->dir[2];
+        ray.org.x = fr->org[0]; ray.org.y = fr->org[1]; ray.org.z = fr->org[2];
+        ray.tmin = fr->t_min; ray.tmax = fr->t_max;
         ray.osi = QR_NULL; ray.oflg = 0;
         ray.ploc = {0, 0, 0};
         ray.list = QR_NULL;
         if (inside)
         {
-            const int tile = (y / fr.tile_h) * fr.tls_row + (x / fr.tile_w);
+            const int tile = (y / fr->tile_h) * fr->tls_row + (x / fr->tile_w);
             ray.list = sc.tiles[tile];
         }
     }
@@ -1352,7 +1362,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
             QR_TICK(tk_rest);
             traverse<false>(sc, tr, ray, h, occ);
             QR_TICK(tk_trav);
-            const bool got = tr && h.si != QR_NULL;
+            const bool got = tr && h.si != QR_NULL && !(sc.dbg & 4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
             if (got && sp == 0) hit_id = (h.si << 1) | h.side;
 
@@ -1374,7 +1384,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
                     f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
                     f.meta = meta | 1;
                     sp++;
-                    ray.org = o.hit; ray.dir = o.tdir; ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                    ray.org = o.hit; ray.dir = o.tdir; ray.tmin = 0.0f; ray.tmax = fr->t_max;
                     ray.list = o.lst_tr; ray.osi = h.si; ray.oflg = h.side | FLAG_PASS_THRU;
                     ray.ploc = o.loc;
                     mode = 0;
@@ -1397,7 +1407,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
                         f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
                         f.meta = meta | 2;
                         sp++;
-                        ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                        ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = fr->t_max;
                         ray.list = o.lst_rf; ray.osi = h.si; ray.oflg = h.side;
                         ray.ploc = o.loc;
                         mode = 0;
@@ -1439,7 +1449,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
                         const int psi = f.meta >> 4, pside = (f.meta >> 3) & 1;
                         ray.org = {f.hit[0], f.hit[1], f.hit[2]};
                         ray.dir = {f.rdir[0], f.rdir[1], f.rdir[2]};
-                        ray.tmin = 0.0f; ray.tmax = fr.t_max;
+                        ray.tmin = 0.0f; ray.tmax = fr->t_max;
                         ray.list = sc.shd[psi].lst[pside * 2 + 1];
                         ray.osi = psi; ray.oflg = pside;
                         ray.ploc = {f.loc[0], f.loc[1], f.loc[2]};
@@ -1485,16 +1495,16 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     }
     if (inside && k == 0)
     {
-        if (fr.ctx_flags & QR_PROP_GAMMA)
+        if (fr->ctx_flags & QR_PROP_GAMMA)
         {
             cr = __builtin_sqrtf(cr); cg = __builtin_sqrtf(cg); cb = __builtin_sqrtf(cb);
         }
-        cr = cr * fr.clamp; cg = cg * fr.clamp; cb = cb * fr.clamp;
-        const u32 p = (((u32)cvt_near(cr) & fr.cmask) << 16) |
-                      (((u32)cvt_near(cg) & fr.cmask) << 8) |
-                       ((u32)cvt_near(cb) & fr.cmask);
-        frame[(size_t)y * fr.frm_w + x] = p;
-        if (ids != nullptr) ids[(size_t)y * fr.frm_w + x] = hit_id;
+        cr = cr * fr->clamp; cg = cg * fr->clamp; cb = cb * fr->clamp;
+        const u32 p = (((u32)cvt_near(cr) & fr->cmask) << 16) |
+                      (((u32)cvt_near(cg) & fr->cmask) << 8) |
+                       ((u32)cvt_near(cb) & fr->cmask);
+        frame[(size_t)y * fr->frm_w + x] = p;
+        if (ids != nullptr) ids[(size_t)y * fr->frm_w + x] = hit_id;
     }
 
     if (COUNT)
