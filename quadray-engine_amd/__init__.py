@@ -59,6 +59,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise QrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(the gfx950 backend has no fallback path)")
+    try:
+        # load torch's bundled HIP runtime first so that libqrhip.so binds to the same libamdhip64
+        # (two HIP runtimes in one process cannot both own the device)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cu64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
     L.qr_last_error.restype = ctypes.c_char_p

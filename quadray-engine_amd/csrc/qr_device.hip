@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
 #include <string>
 
 #define HIP_TRY(expr)                                                          \
@@ -45,6 +46,124 @@ extern "C" int qr_device_count(void)
 }
 
 static size_t pad16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+/*
+ * Conservative WORLD-space bounding sphere of the visible part of surface `i`, derived from
+ * the snapshot only (clip box, shape coefficients, transform).  r = +inf when no bound can be
+ * shown.  Used by the list walk purely as a wave-level cull: an element is skipped when every
+ * ray of the group provably misses the sphere (QR_CULL in qr_kernel.hpp), so a wrong "inf" costs
+ * time, never correctness; the radius is inflated so that fp32 rounding in the device test and
+ * in the reference's hit points cannot turn a real hit into a cull.
+ */
+struct BSphere { float c[3]; float r; };
+
+static BSphere bound_sphere(const qr_scene_view &v, int i)
+{
+    const double INF = 1e300;
+    BSphere out = { {0.0f, 0.0f, 0.0f}, __builtin_inff() };
+    const qr_surface &q = v.srf[i];
+    if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) return out;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++)
+    {
+        lo[k] = (q.minmax_t & (1u << k)) ? (double)q.min[k] : -INF;
+        hi[k] = (q.minmax_t & (1u << (3 + k))) ? (double)q.max[k] : INF;
+        if (lo[k] > hi[k]) { lo[k] = hi[k] = 0.5 * (lo[k] + hi[k]); }    /* empty box: nothing visible */
+    }
+    const int solver = q.srf_t[0];
+    if (solver == 1)
+    {
+        const int k = (int)((q.axes >> 4) & 3);
+        if (k > 2) return out;
+        lo[k] = lo[k] > 0.0 ? lo[k] : (hi[k] < 0.0 ? hi[k] : 0.0);
+        hi[k] = lo[k];
+        lo[k] -= 1e-3; hi[k] += 1e-3;
+    }
+    else if (solver == 2 || solver == 3)
+    {
+        /* sum_a sci_a x_a^2 - 2 sum_a scj_a x_a = sci_w  ->  for an axis with sci_a > 0, scj_a == 0:
+         * sci_a x_a^2 <= sci_w + sum_{b != a} [ max(2 scj_b x_b) + max(-sci_b x_b^2) ] over the box */
+        for (int pass = 0; pass < 3; pass++)
+            for (int a = 0; a < 3; a++)
+            {
+                const double sa = q.sci[a];
+                if (!(sa > 0.0) || q.scj[a] != 0.0f) continue;
+                double rhs = q.sci[3];
+                bool ok = true;
+                for (int b = 0; b < 3 && ok; b++)
+                {
+                    if (b == a) continue;
+                    const double sb = q.sci[b], jb = q.scj[b];
+                    if (jb != 0.0)
+                    {
+                        const double e0 = 2.0 * jb * lo[b], e1 = 2.0 * jb * hi[b];
+                        const double m = e0 > e1 ? e0 : e1;
+                        if (!(m < INF / 4)) ok = false; else rhs += m;
+                    }
+                    if (sb < 0.0)
+                    {
+                        const double x2 = (lo[b] * lo[b] > hi[b] * hi[b]) ? lo[b] * lo[b] : hi[b] * hi[b];
+                        if (!(x2 < INF / 4)) ok = false; else rhs += -sb * x2;
+                    }
+                    /* sb >= 0: -sb x_b^2 <= 0, dropped */
+                }
+                if (!ok) continue;
+                const double lim = __builtin_sqrt((rhs > 0.0 ? rhs : 0.0) / sa) * 1.0005 + 1e-4;
+                if (lo[a] < -lim) lo[a] = -lim;
+                if (hi[a] > lim) hi[a] = lim;
+                if (lo[a] > hi[a]) lo[a] = hi[a] = 0.5 * (lo[a] + hi[a]);
+            }
+    }
+    else
+    {
+        return out;
+    }
+    for (int k = 0; k < 3; k++) if (!(lo[k] > -INF / 4) || !(hi[k] < INF / 4)) return out;
+
+    double cl[3], r2 = 0.0;
+    for (int k = 0; k < 3; k++) { cl[k] = 0.5 * (lo[k] + hi[k]); const double h = 0.5 * (hi[k] - lo[k]); r2 += h * h; }
+    double rl = __builtin_sqrt(r2);
+    double cw[3];
+    if (q.has_trm == 0)
+    {
+        for (int k = 0; k < 3; k++) cw[k] = (double)q.pos[k] + cl[k];
+    }
+    else
+    {
+        if (q.trnode < 0) return out;
+        const qr_surface &t = v.srf[q.trnode];
+        double m[3][3] = { { t.tci[0], t.tci[1], t.tci[2] }, { t.tcj[0], t.tcj[1], t.tcj[2] }, { t.tck[0], t.tck[1], t.tck[2] } };
+        if (t.has_trm == 1) { m[0][1] = m[0][2] = m[1][0] = m[1][2] = m[2][0] = m[2][1] = 0.0; }
+        const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1])
+                         - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                         + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+        if (!(det > 1e-12 || det < -1e-12)) return out;
+        double inv[3][3];
+        inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det;
+        inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+        inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+        inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
+        inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det;
+        inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+        inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det;
+        inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+        inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+        double pl[3];       /* point in the trnode's frame */
+        for (int k = 0; k < 3; k++) pl[k] = cl[k] + (q.trnode == i ? 0.0 : (double)q.pos[k]);
+        double fro = 0.0;
+        for (int a = 0; a < 3; a++)
+        {
+            cw[a] = (double)t.pos[a];
+            for (int b = 0; b < 3; b++) { cw[a] += inv[a][b] * pl[b]; fro += inv[a][b] * inv[a][b]; }
+        }
+        rl *= __builtin_sqrt(fro);
+    }
+    const double r = rl * 1.002 + 2e-3;
+    if (!(r < 1e30)) return out;
+    for (int k = 0; k < 3; k++) { if (!(cw[k] > -1e30 && cw[k] < 1e30)) return out; out.c[k] = (float)cw[k]; }
+    out.r = (float)r * 1.0001f + 1e-6f;
+    return out;
+}
 
 extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene **out)
 {
@@ -135,26 +254,96 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                 if (const char *m = check_list(v.elm[e].data, 0)) return qr_fail(QR_ERR_ARG, m);
     }
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
-    if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
+    /* ---- 1. build every device array on the host ---------------------------------------- */
 
-    qr_device_scene *s = new qr_device_scene();
-    memset(s, 0, sizeof(*s));
-    s->device = device;
-    s->hdr = *v.hdr;
+    /* surfaces: repack qr_surface (256 B, snapshot layout) into DSurf (128 B, hot part first)
+     * for the list walk and DShade for shading */
+    std::vector<DSurf> dsurf(n_srf + 1);
+    std::vector<DShade> dshade(n_srf + 1);
+    memset(dsurf.data(), 0, dsurf.size() * sizeof(DSurf));
+    memset(dshade.data(), 0, dshade.size() * sizeof(DShade));
+    for (int i = 0; i < n_srf; i++)
+    {
+        const qr_surface &q = v.srf[i];
+        const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
+        if (real && q.smask != QR_SMASK) return qr_fail(QR_ERR_ARG, "surface smask is not the fp32 sign bit");
+        if (real && ((q.shift != 0) != (q.has_trm != 0)))
+            return qr_fail(QR_ERR_UNSUP, "surface with trnode shift but no transform flags (or the reverse)");
+        if ((q.conic & ~3) || (q.has_trm & ~3) || (q.srf_t[0] & ~3) || (q.srf_t[1] & ~3) || (q.srf_t[2] & ~3))
+            return qr_fail(QR_ERR_ARG, "surface tag fields out of range");
+        DSurf &d = dsurf[i];
+        DShade &h = dshade[i];
+        for (int k = 0; k < 3; k++)
+        {
+            d.pos[k] = q.pos[k]; d.scj[k] = q.scj[k];
+            /* an axis without clipping gets an infinite bound: the kernel compares unconditionally */
+            d.min[k] = (q.minmax_t & (1u << k)) ? q.min[k] : -__builtin_inff();
+            d.max[k] = (q.minmax_t & (1u << (3 + k))) ? q.max[k] : __builtin_inff();
+            d.tci[k] = q.tci[k]; d.tcj[k] = q.tcj[k]; d.tck[k] = q.tck[k];
+        }
+        for (int k = 0; k < 4; k++) d.sci[k] = q.sci[k];
+        d.clip = q.clip; d.d_eps = q.d_eps; d.t_eps = q.t_eps;
+        d.trnode = q.trnode;
+        d.props0 = q.props[0]; d.props1 = q.props[1];
+        h.mat[0] = q.mat[0] >= 0 ? q.mat[0] : 0; h.mat[1] = q.mat[1] >= 0 ? q.mat[1] : 0;
+        uint32_t f = 0;
+        f |= q.minmax_t & 63u;
+        f |= ((uint32_t)q.conic & 3u) << 6;
+        f |= ((uint32_t)q.has_trm & 3u) << 8;
+        f |= (q.shift ? 1u : 0u) << 10;
+        f |= ((q.axes >> 0) & 3u) << 11; f |= ((q.axes >> 2) & 3u) << 13; f |= ((q.axes >> 4) & 3u) << 15;
+        f |= ((q.axes >> 8) & 7u) << 17;
+        f |= (real ? ((uint32_t)q.srf_t[0] & 3u) : 0u) << 20;
+        f |= ((uint32_t)q.srf_t[1] & 3u) << 22;
+        f |= ((uint32_t)q.srf_t[2] & 3u) << 24;
+        f |= (q.srf_t[3] < 0 ? 1u : 0u) << 26;
+        f |= (q.c_def != 0 ? 1u : 0u) << 28;
+        d.flags = f;
+    }
 
-    /* one device allocation; each array padded by one zero record so that
-     * masked-off lanes may read index 0 of an empty array */
-    size_t o_srf = 0;
-    size_t o_shd = pad16(o_srf + (size_t)(n_srf + 1) * sizeof(DSurf));
-    size_t o_mat = pad16(o_shd + (size_t)(n_srf + 1) * sizeof(DShade));
-    size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
-    size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
-    size_t o_til = pad16(o_elm + (size_t)(n_elm + 1) * sizeof(qr_elem));
-    size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
+    /* bounding spheres + cull flag (bit 2 of a surface-list cell's kind) */
+    std::vector<BSphere> bsph(n_srf + 1);
+    memset(bsph.data(), 0, bsph.size() * sizeof(BSphere));
+    for (int i = 0; i < n_srf; i++) bsph[i] = bound_sphere(v, i);
+    if (getenv("QR_VERBOSE"))
+    {
+        int nreal = 0, nfin = 0;
+        for (int i = 0; i < n_srf; i++)
+        {
+            const qr_surface &q = v.srf[i];
+            if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+            nreal++; if (bsph[i].r < 1e30f) nfin++;
+        }
+        fprintf(stderr, "bounding spheres: %d of %d real surfaces bounded\n", nfin, nreal);
+    }
+    std::vector<qr_elem> cells(n_elm + 1);
+    memset(cells.data(), 0, cells.size() * sizeof(qr_elem));
+    memcpy(cells.data(), v.elm, (size_t)n_elm * sizeof(qr_elem));
+    {
+        std::vector<uint8_t> seen(n_elm + 1, 0);
+        auto mark_list = [&](int head) {
+            for (int e = head; e != QR_NULL && !seen[e]; e = v.elm[e].next)
+            {
+                seen[e] = 1;
+                const int si = v.elm[e].simd;
+                const qr_surface &q = v.srf[si];
+                const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
+                if (real && (v.elm[e].kind & 3) == 0 && bsph[si].r < 1e30f && !getenv("QR_NOCULL")) cells[e].kind |= 4;
+            }
+        };
+        for (uint32_t i = 0; i < v.hdr->n_tiles; i++) mark_list(v.tiles[i]);
+        mark_list(fr.clist);
+        for (int i = 0; i < n_srf; i++)
+        {
+            const qr_surface &q = v.srf[i];
+            if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+            mark_list(q.lst[1]); mark_list(q.lst[3]);
+            for (int side = 0; side < 2; side++)
+                for (int e = q.lst[side * 2]; e != QR_NULL; e = v.elm[e].next) mark_list(v.elm[e].data);
+        }
+    }
+    for (int i = 0; i < n_srf; i++) for (int k = 0; k < 4; k++) dshade[i].lst[k] = v.srf[i].lst[k];
+
     /* wave schedule: one entry per wave footprint (8x8 / 8x4 / 4x4 pixels) */
     const int fw = fr.fsaa == 2 ? 4 : 8, fh = fr.fsaa == 0 ? 8 : 4;
     const int nbx = (fr.frm_w + fw - 1) / fw, nby = (fr.frm_h + fh - 1) / fh;
@@ -181,64 +370,50 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                     {
                         const int bx = tx * gx + i, by = ty * gy + j;
                         if (bx >= nbx || by >= nby) continue;
-                        const int px = bx * fw, py = by * fh;
-                        const int tlx = px / fr.tile_w, tly = py / fr.tile_h;
+                        const int tlx = (bx * fw) / fr.tile_w, tly = (by * fh) / fr.tile_h;
                         const bool hv = tlx < fr.tls_row && tly < fr.tls_col && tile_heavy[(size_t)tly * fr.tls_row + tlx];
                         (hv ? heavy : light).push_back((uint32_t)bx | ((uint32_t)by << 16));
                     }
         order = heavy;
         order.insert(order.end(), light.begin(), light.end());
     }
+
+    /* ---- 2. one device allocation; arrays padded by one zero record so that masked-off
+     *         lanes may read index 0 of an empty array ------------------------------------ */
+    size_t o_srf = 0;
+    size_t o_shd = pad16(o_srf + dsurf.size() * sizeof(DSurf));
+    size_t o_mat = pad16(o_shd + dshade.size() * sizeof(DShade));
+    size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
+    size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
+    size_t o_til = pad16(o_elm + cells.size() * sizeof(qr_elem));
+    size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
     size_t o_ord = pad16(o_tex + (size_t)(n_tex + 1) * 4);
     size_t o_frm = pad16(o_ord + order.size() * 4 + 16);
-    size_t total = pad16(o_frm + sizeof(qr_frame));
+    size_t o_bs = pad16(o_frm + sizeof(qr_frame));
+    size_t total = pad16(o_bs + bsph.size() * sizeof(BSphere));
 
     std::vector<uint8_t> host(total, 0);
-    /* repack qr_surface (256 B, snapshot layout) into the device records:
-     * DSurf (128 B, hot part first) for the list walk, DShade for shading */
-    for (int i = 0; i < n_srf; i++)
-    {
-        const qr_surface &q = v.srf[i];
-        if (q.smask != QR_SMASK && q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX) { delete s; return qr_fail(QR_ERR_ARG, "surface smask is not the fp32 sign bit"); }
-        DSurf d; memset(&d, 0, sizeof(d));
-        DShade h; memset(&h, 0, sizeof(h));
-        for (int k = 0; k < 3; k++)
-        {
-            d.pos[k] = q.pos[k]; d.scj[k] = q.scj[k]; d.min[k] = q.min[k]; d.max[k] = q.max[k];
-            d.tci[k] = q.tci[k]; d.tcj[k] = q.tcj[k]; d.tck[k] = q.tck[k];
-        }
-        for (int k = 0; k < 4; k++) { d.sci[k] = q.sci[k]; h.lst[k] = q.lst[k]; }
-        d.clip = q.clip; d.d_eps = q.d_eps; d.t_eps = q.t_eps;
-        d.trnode = q.trnode;
-        d.props0 = q.props[0]; d.props1 = q.props[1];
-        h.mat[0] = q.mat[0] >= 0 ? q.mat[0] : 0; h.mat[1] = q.mat[1] >= 0 ? q.mat[1] : 0;
-        const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
-        uint32_t f = 0;
-        f |= q.minmax_t & 63u;
-        f |= ((uint32_t)q.conic & 3u) << 6;
-        f |= ((uint32_t)q.has_trm & 3u) << 8;
-        f |= (q.shift ? 1u : 0u) << 10;
-        f |= ((q.axes >> 0) & 3u) << 11; f |= ((q.axes >> 2) & 3u) << 13; f |= ((q.axes >> 4) & 3u) << 15;
-        f |= ((q.axes >> 8) & 7u) << 17;
-        f |= (real ? ((uint32_t)q.srf_t[0] & 3u) : 0u) << 20;
-        f |= ((uint32_t)q.srf_t[1] & 3u) << 22;
-        f |= ((uint32_t)q.srf_t[2] & 3u) << 24;
-        f |= (q.srf_t[3] < 0 ? 1u : 0u) << 26;
-        f |= (q.c_def != 0 ? 1u : 0u) << 28;
-        d.flags = f;
-        if ((q.conic & ~3) || (q.has_trm & ~3) || (q.srf_t[0] & ~3) || (q.srf_t[1] & ~3) || (q.srf_t[2] & ~3))
-        { delete s; return qr_fail(QR_ERR_ARG, "surface tag fields out of range"); }
-        memcpy(host.data() + o_srf + (size_t)i * sizeof(DSurf), &d, sizeof(d));
-        memcpy(host.data() + o_shd + (size_t)i * sizeof(DShade), &h, sizeof(h));
-    }
+    memcpy(host.data() + o_srf, dsurf.data(), dsurf.size() * sizeof(DSurf));
+    memcpy(host.data() + o_shd, dshade.data(), dshade.size() * sizeof(DShade));
     memcpy(host.data() + o_mat, v.mat, (size_t)n_mat * sizeof(qr_material));
     memcpy(host.data() + o_lgt, v.lgt, (size_t)n_lgt * sizeof(qr_light));
-    memcpy(host.data() + o_elm, v.elm, (size_t)n_elm * sizeof(qr_elem));
+    memcpy(host.data() + o_elm, cells.data(), cells.size() * sizeof(qr_elem));
     memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
     memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
     memcpy(host.data() + o_ord, order.data(), order.size() * 4);
     memcpy(host.data() + o_frm, &fr, sizeof(qr_frame));
+    memcpy(host.data() + o_bs, bsph.data(), bsph.size() * sizeof(BSphere));
 
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    qr_device_scene *s = new qr_device_scene();
+    memset(s, 0, sizeof(*s));
+    s->device = device;
+    s->hdr = *v.hdr;
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
@@ -257,6 +432,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     s->sc.elm = (const qr_elem *)(d + o_elm);
     s->sc.tiles = (const int32_t *)(d + o_til);
     s->sc.texels = (const uint32_t *)(d + o_tex);
+    s->sc.bsph = (const void *)(d + o_bs);
     s->sc.order = (const uint32_t *)(d + o_ord);
     s->sc.n_blocks = (int32_t)order.size();
     s->sc.stats = s->d_counters + 4;
@@ -376,6 +552,16 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
+#ifdef QR_STATS2
+    {
+        unsigned long long st[12];
+        HIP_TRY(hipMemcpy(st, s->d_counters + 4, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "QR_STATS2 clip calls %llu: cycles per call: depth/hit/conic/minmax %.0f, custom clippers %.0f\n", st[11], st[9] / (st[11] + 1e-9), st[10] / (st[11] + 1e-9));
+        const double ni = st[3] + 1e-9, nf = st[4] + 1e-9;
+        fprintf(stderr, "QR_STATS2 shadow walks: iterations %llu (full %llu): cycles/iteration: cell load %.0f, cull %.0f; per full element %.0f = hot load %.0f + diff/transform %.0f + solver %.0f + candidates/clip %.0f\n",
+                st[3], st[4], st[0] / ni, st[1] / ni, st[2] / nf, st[5] / nf, st[6] / nf, st[7] / nf, st[8] / nf);
+    }
+#endif
 #ifdef QR_STATS
     {
         unsigned long long st[12];

@@ -113,6 +113,7 @@ struct DevScene
     int32_t row_begin, row_end;   /* rows rendered by this launch            */
     int32_t index, thnum;         /* reference row interleave                */
     int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
+    const void        *__restrict__ bsph;   /* float4 per surface: world-space bounding sphere (cx,cy,cz,r) */
     const uint32_t    *__restrict__ order;  /* block schedule: bx | by << 16, heavy tiles first */
     int32_t n_blocks;
     unsigned long long *stats;    /* QR_STATS builds only: walk statistics */
@@ -136,6 +137,15 @@ __device__ __forceinline__ bool cge(float a, float b) { return !(a < b); }
 __device__ __forceinline__ float fxor(float a, u32 m) { return u2f(f2u(a) ^ m); }
 __device__ __forceinline__ float fabs_bits(float a)   { return u2f(f2u(a) & 0x7FFFFFFFu); }
 __device__ __forceinline__ float rsq(float x) { return 1.0f / __builtin_sqrtf(x); }
+
+/*
+ * Lane mask in a VGPR (0 / ~0), the reference's own representation.  Chains of `bool && bool`
+ * compile to v_cmp -> s_and_b64 chains through SGPR pairs, each link a VALU->SALU round trip
+ * (measured: ~20 cycles per link, the depth/min-max tests of CC_clp took ~570 cycles); as VGPR
+ * words the same logic is v_cmp + v_cndmask + v_and.  The empty asm keeps the optimiser from
+ * folding the words back into i1 logic.
+ */
+__device__ __forceinline__ u32 LM(bool c) { u32 x = c ? 0xFFFFFFFFu : 0u; asm("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ int32_t cvt_floor(float x)
 {
@@ -291,22 +301,31 @@ __device__ __forceinline__ float hsci(const Hot &s, int i)
 }
 
 /* ------------------------------------------------------------------------ */
+#ifdef QR_STATS2
+#define QR_TT(x) x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#endif
 /* CC_clp, tracer.cpp:1597-2160.  `s`, `P` and the clipper list are          */
 /* wave-uniform; every temporary is local to the call.  `loc` returns the    */
 /* local hit (ctx_NEW_* of the surface's space).                             */
 /* ------------------------------------------------------------------------ */
 
-__device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
+__device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
                                      const Ray &r, const Walk &w, const V3 &ry, const V3 &df,
-                                     bool dmask, u32 amask, float t, int side, bool m, V3 &loc)
+                                     bool dmask, u32 amask, float t, int side, u32 m, V3 &loc
+#ifdef QR_STATS2
+                                     , unsigned long long *g_clip
+#endif
+                                     )
 {
+#ifdef QR_STATS2
+    unsigned long long g_c; g_c = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const u32 fl = s.flags;
     const int has_trm = (int)DF_TRM(fl);
     float x4, x5, x6;
     V3 hit;
 
-    m = m && cgt(w.tbuf, t);
-    m = m && clt(r.tmin, t);
+    m &= LM(cgt(w.tbuf, t)) & LM(clt(r.tmin, t));
 
     x4 = r.dir.x * t; x4 = x4 + r.org.x; hit.x = x4;
     x5 = r.dir.y * t; x5 = x5 + r.org.y; hit.y = x5;
@@ -383,22 +402,22 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
     }
     loc = nw;
 
-    /* axis min/max, 1874-1927 */
-    const u32 mm = DF_MINMAX(fl);
-    if (mm & 0x01) m = m && cle(s.min0, x4);
-    if (mm & 0x08) m = m && cge(s.max0, x4);
-    if (mm & 0x02) m = m && cle(s.min1, x5);
-    if (mm & 0x10) m = m && cge(s.max1, x5);
-    if (mm & 0x04) m = m && cle(s.min2, x6);
-    if (mm & 0x20) m = m && cge(s.max2, x6);
+    /* axis min/max, 1874-1927: the upload replaces the bound of an unclipped axis by -inf/+inf,
+     * which makes the six compares unconditional (a lane still in `m` has a finite hit point) */
+    m &= LM(cle(s.min0, x4)) & LM(cge(s.max0, x4));
+    m &= LM(cle(s.min1, x5)) & LM(cge(s.max1, x5));
+    m &= LM(cle(s.min2, x6)) & LM(cge(s.max2, x6));
 
+#ifdef QR_STATS2
+    { unsigned long long t_; QR_TT(t_); g_clip[0] += t_ - g_c; g_c = t_; g_clip[2] += 1; }
+#endif
     /* custom clipping, 1931-2151 */
     int e = s.clip;
-    if (e != QR_NULL && __any(m))
+    if (e != QR_NULL && __any(m != 0))
     {
         int redx = QR_NULL;
         const int local_lst = P->trnode;
-        bool c_acc = false;
+        u32 c_acc = 0;
         V3 cxyz = {0.0f, 0.0f, 0.0f}, cijk = {0.0f, 0.0f, 0.0f};   /* ctx_NRM_* as clip temporaries */
         while (e != QR_NULL)
         {
@@ -407,8 +426,8 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
             const int enext = el.next;
             if (el.simd == QR_NULL)
             {
-                if (el.data > 0) { m = !m && c_acc; }
-                else             { c_acc = m; m = DF_CDEF(fl) != 0; }
+                if (el.data > 0) { m = ~m & c_acc; }
+                else             { c_acc = m; m = DF_CDEF(fl) != 0 ? 0xFFFFFFFFu : 0u; }
                 e = enext;
                 continue;
             }
@@ -490,13 +509,15 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
                 }
                 if (ok)
                 {
-                    const bool rr = el.data < 0 ? cge(f4, 0.0f) : cle(f4, 0.0f);
-                    m = m && rr;
+                    m &= LM(el.data < 0 ? cge(f4, 0.0f) : cle(f4, 0.0f));
                 }
             }
             e = enext;
         }
     }
+#ifdef QR_STATS2
+    { unsigned long long t_; QR_TT(t_); g_clip[1] += t_ - g_c; }
+#endif
     return m;
 }
 
@@ -508,13 +529,24 @@ __device__ __forceinline__ bool clip(const DevScene &sc, const Hot &s, SrfP P,
 
 template <bool SHADOW>
 __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, const qr_elem &el, SrfP P,
-                                             const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live)
+                                             const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live
+#ifdef QR_STATS2
+                                             , unsigned long long *g_seg
+#endif
+                                             )
 {
+#ifdef QR_STATS2
+    unsigned long long g_t; QR_TT(g_t);
+#endif
     const bool on = live && w.resume == QR_NULL;
 
     if (__any(on))
     {
         const Hot s = ld_hot5(P);
+#ifdef QR_STATS2
+        asm volatile("" :: "s"(s.flags), "s"(s.max2));
+        { unsigned long long t_; QR_TT(t_); g_seg[0] += t_ - g_t; g_t = t_; }
+#endif
         const int si = el.simd;
         const u32 fl = s.flags;
         const bool is_arr = DF_ARRAY(fl) != 0;
@@ -564,6 +596,9 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
                 if (do_ray) w.rijk = xform(P, has_trm, r.dir);
             }
 
+#ifdef QR_STATS2
+            { unsigned long long t_; QR_TT(t_); g_seg[1] += t_ - g_t; g_t = t_; }
+#endif
             const V3 ry = sh ? w.rijk : r.dir;
             const V3 df = sh ? w.dijk : w.dxyz;
 
@@ -708,17 +743,24 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
                     }
                 }
 
+#ifdef QR_STATS2
+                { unsigned long long t_; QR_TT(t_); g_seg[2] += t_ - g_t; g_t = t_; }
+#endif
                 bool done = false;
 #pragma nounroll
                 for (int p = 0; p < ncand; p++)
                 {
                     const float t = p == 0 ? ct0 : ct1;
                     const int side = p == 0 ? cs0 : cs1;
-                    bool m = (p == 0 ? cm0 : cm1) && !done;
-                    if (!__any(m) || (SHADOW && (sc.dbg & 16))) continue;
+                    u32 m = ((p == 0 ? cm0 : cm1) && !done) ? 0xFFFFFFFFu : 0u;
+                    if (!__any(m != 0) || (SHADOW && (sc.dbg & 16))) continue;
                     V3 loc;
-                    m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc);
-                    if (m)
+                    m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc
+#ifdef QR_STATS2
+                             , g_seg + 4
+#endif
+                             );
+                    if (m != 0)
                     {
                         done = true;
                         if (SHADOW)
@@ -742,6 +784,9 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
         }
     }
 
+#ifdef QR_STATS2
+    { unsigned long long t_; QR_TT(t_); g_seg[3] += t_ - g_t; g_t = t_; }
+#endif
     if (w.resume == e) w.resume = QR_NULL;
 }
 
@@ -760,39 +805,89 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     bool live = true;
     const ElmP E = c_elm(sc);
     const SrfP D = c_srf(sc);
-
+    const QR_CONST u32x4 *const BS = (const QR_CONST u32x4 *)sc.bsph;
     int e = __builtin_amdgcn_readfirstlane(head);
+    const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
+    const float dlen = __builtin_sqrtf(dd);
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0;
 #endif
-#if QR_PIPE == 1
-    /* the 16-byte list cell of the next element is fetched while this one is intersected */
-    qr_elem el = ld_elem(E + e);
-    for (;;)
-    {
-        const bool has_next = el.next != QR_NULL;
-        qr_elem el1 = el;
-        if (has_next) el1 = ld_elem(E + el.next);
-#ifdef QR_STATS
-        st_iter++; st_lanes += __popcll(__ballot(live && w.resume == QR_NULL));
-#endif
-        walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live);
-        if (SHADOW && !__any(live)) break;
-        if (!has_next) break;
-        e = el.next;
-        el = el1;
-    }
+#ifdef QR_STATS2
+    unsigned long long tA = 0, tB = 0, tC = 0, nA = 0, nC = 0, t0, t1;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QR_T(x) x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
 #else
+#define QR_T(x)
+#endif
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
+        QR_T(t0);
         const qr_elem el = ld_elem(E + e);
+#ifdef QR_STATS2
+        asm volatile("" :: "s"(el.simd), "s"(el.next));
+        QR_T(t1); tA += t1 - t0; nA++; t0 = t1;
+#endif
 #ifdef QR_STATS
         st_iter++; st_lanes += __popcll(__ballot(live && w.resume == QR_NULL));
 #endif
-        walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live);
+        /*
+         * Wave-level cull (ours, not in the reference): `bsph` holds a conservative world-space
+         * bounding sphere of each surface's visible part (16 B per surface, scalar-cache
+         * resident); if every live ray of the group provably misses it (perpendicular distance,
+         * behind the origin, or beyond the current depth bound) the element cannot produce a hit
+         * and is skipped without touching its 128-byte record.  Never applied to array /
+         * bounding-volume cells or to a ray's own surface.
+         */
+        bool skip = false;
+        if (el.kind & 4)
+        {
+            const u32x4 bs = BS[el.simd];
+            const float R = u2f(bs.w);
+            const float ocx = u2f(bs.x) - r.org.x, ocy = u2f(bs.y) - r.org.y, ocz = u2f(bs.z) - r.org.z;
+            const float b = ocx * r.dir.x + ocy * r.dir.y + ocz * r.dir.z;
+            const float crx = ocy * r.dir.z - ocz * r.dir.y;
+            const float cry = ocz * r.dir.x - ocx * r.dir.z;
+            const float crz = ocx * r.dir.y - ocy * r.dir.x;
+            const float R2 = R * R;
+            const bool outside = (ocx * ocx + ocy * ocy + ocz * ocz) > 1.01f * R2;
+            const bool miss = (crx * crx + cry * cry + crz * crz) > dd * R2
+                           || (outside && b < 0.0f)
+                           || (b - R * dlen) > w.tbuf * dd;
+            const bool need = live && w.resume == QR_NULL && !(miss && el.simd != r.osi);
+            skip = !__any(need);
+        }
+#ifdef QR_STATS2
+        QR_T(t1); tB += t1 - t0; t0 = t1;
+#endif
+        if (skip)
+        {
+#ifdef QR_STATS
+            st_lanes += 1000000ull;
+#endif
+            if (e == w.local_obj) w.local_obj = QR_NULL;
+            if (w.resume == e) w.resume = QR_NULL;
+        }
+        else
+        {
+            walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live
+#ifdef QR_STATS2
+                                 , seg
+#endif
+                                 );
+#ifdef QR_STATS2
+            QR_T(t1); tC += t1 - t0; nC++;
+#endif
+        }
         if (SHADOW && !__any(live)) break;
         e = el.next;
+    }
+#ifdef QR_STATS2
+    if (SHADOW && __ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        atomicAdd(&sc.stats[0], tA); atomicAdd(&sc.stats[1], tB); atomicAdd(&sc.stats[2], tC);
+        atomicAdd(&sc.stats[3], nA); atomicAdd(&sc.stats[4], nC);
+        atomicAdd(&sc.stats[5], seg[0]); atomicAdd(&sc.stats[6], seg[1]); atomicAdd(&sc.stats[7], seg[2]); atomicAdd(&sc.stats[8], seg[3]); atomicAdd(&sc.stats[9], seg[4]); atomicAdd(&sc.stats[10], seg[5]); atomicAdd(&sc.stats[11], seg[6]);
     }
 #endif
 #ifdef QR_STATS
