@@ -321,6 +321,8 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     memcpy(cells.data(), v.elm, (size_t)n_elm * sizeof(qr_elem));
     {
         std::vector<uint8_t> seen(n_elm + 1, 0);
+        const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
+        const int cull_mode = getenv("QR_NOCULL") ? 0 : (cm ? atoi(cm) : 2);
         auto mark_list = [&](int head) {
             for (int e = head; e != QR_NULL && !seen[e]; e = v.elm[e].next)
             {
@@ -328,7 +330,11 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                 const int si = v.elm[e].simd;
                 const qr_surface &q = v.srf[si];
                 const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
-                if (real && (v.elm[e].kind & 3) == 0 && bsph[si].r < 1e30f && !getenv("QR_NOCULL")) cells[e].kind |= 4;
+                /* the solver already rejects a ray that misses a closed quadric as cheaply as the sphere test
+                 * does; the test pays for planes and open quadrics, whose hits die only in the clippers */
+                const bool open_shape = q.srf_t[0] == 1 || !(q.sci[0] > 0.0f && q.sci[1] > 0.0f && q.sci[2] > 0.0f);
+                const bool want = cull_mode >= 3 || (cull_mode == 2 && open_shape) || (cull_mode == 1 && q.srf_t[0] == 1);
+                if (real && (v.elm[e].kind & 3) == 0 && bsph[si].r < 1e30f && want) cells[e].kind |= 4;
             }
         };
         for (uint32_t i = 0; i < v.hdr->n_tiles; i++) mark_list(v.tiles[i]);
@@ -385,7 +391,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     size_t o_mat = pad16(o_shd + dshade.size() * sizeof(DShade));
     size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
     size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
-    size_t o_til = pad16(o_elm + cells.size() * sizeof(qr_elem));
+    size_t o_til = pad16(o_elm + cells.size() * sizeof(DCell));
     size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
     size_t o_ord = pad16(o_tex + (size_t)(n_tex + 1) * 4);
     size_t o_frm = pad16(o_ord + order.size() * 4 + 16);
@@ -397,7 +403,21 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     memcpy(host.data() + o_shd, dshade.data(), dshade.size() * sizeof(DShade));
     memcpy(host.data() + o_mat, v.mat, (size_t)n_mat * sizeof(qr_material));
     memcpy(host.data() + o_lgt, v.lgt, (size_t)n_lgt * sizeof(qr_light));
-    memcpy(host.data() + o_elm, cells.data(), cells.size() * sizeof(qr_elem));
+    {
+        std::vector<DCell> dc(cells.size());
+        for (size_t i = 0; i < cells.size(); i++)
+        {
+            DCell &c = dc[i];
+            c.simd = cells[i].simd; c.data = cells[i].data; c.next = cells[i].next; c.kind = cells[i].kind;
+            c.cx = c.cy = c.cz = 0.0f; c.r = __builtin_inff();
+            if ((c.kind & 4) && c.simd >= 0 && c.simd < n_srf)
+            {
+                const BSphere &b = bsph[c.simd];
+                c.cx = b.c[0]; c.cy = b.c[1]; c.cz = b.c[2]; c.r = b.r;
+            }
+        }
+        memcpy(host.data() + o_elm, dc.data(), dc.size() * sizeof(DCell));
+    }
     memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
     memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
     memcpy(host.data() + o_ord, order.data(), order.size() * 4);
@@ -429,7 +449,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     s->sc.shd = (const DShade *)(d + o_shd);
     s->sc.mat = (const qr_material *)(d + o_mat);
     s->sc.lgt = (const qr_light *)(d + o_lgt);
-    s->sc.elm = (const qr_elem *)(d + o_elm);
+    s->sc.elm = (const DCell *)(d + o_elm);
     s->sc.tiles = (const int32_t *)(d + o_til);
     s->sc.texels = (const uint32_t *)(d + o_tex);
     s->sc.bsph = (const void *)(d + o_bs);

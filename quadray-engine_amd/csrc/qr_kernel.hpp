@@ -99,13 +99,21 @@ struct DShade
     int32_t pad[2];
 };
 
+/* device list cell: the snapshot's qr_elem plus the conservative world-space bounding sphere
+ * of the cell's surface (one 32-byte scalar load serves both the walk and its cull test) */
+struct DCell
+{
+    int32_t simd, data, next, kind;     /* kind bit 2: cullable (finite bound, plain surface cell) */
+    float cx, cy, cz, r;
+};
+
 struct DevScene
 {
     const DSurf       *__restrict__ srf;
     const DShade      *__restrict__ shd;
     const qr_material *__restrict__ mat;
     const qr_light    *__restrict__ lgt;
-    const qr_elem     *__restrict__ elm;
+    const DCell       *__restrict__ elm;    /* list cells, 32 B: {simd,data,next,kind | bounding sphere} */
     const int32_t     *__restrict__ tiles;
     const uint32_t    *__restrict__ texels;
     const qr_frame    *__restrict__ frp;    /* frame/camera parameters (device memory, scalar-loaded on demand) */
@@ -177,7 +185,7 @@ __device__ __forceinline__ void  vset(V3 &v, int i, float f)
  */
 #define QR_CONST __attribute__((address_space(4)))
 typedef const QR_CONST DSurf   *SrfP;
-typedef const QR_CONST qr_elem *ElmP;
+typedef const QR_CONST DCell *ElmP;
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
@@ -192,6 +200,17 @@ __device__ __forceinline__ qr_elem ld_elem(ElmP p)
     qr_elem e;
     e.simd = p->simd; e.data = p->data; e.next = p->next; e.kind = p->kind;
     return e;
+}
+struct CellS { qr_elem el; float cx, cy, cz, r; };
+typedef u32 u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ CellS ld_cell(ElmP p)
+{
+    const QR_CONST u32x4_ *q = (const QR_CONST u32x4_ *)p;
+    const u32x4_ a = q[0], b = q[1];
+    CellS c;
+    c.el.simd = (int)a.x; c.el.data = (int)a.y; c.el.next = (int)a.z; c.el.kind = (int)a.w;
+    c.cx = u2f(b.x); c.cy = u2f(b.y); c.cz = u2f(b.z); c.r = u2f(b.w);
+    return c;
 }
 
 /* the hot part of a surface record, held in SGPRs */
@@ -805,7 +824,6 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     bool live = true;
     const ElmP E = c_elm(sc);
     const SrfP D = c_srf(sc);
-    const QR_CONST u32x4 *const BS = (const QR_CONST u32x4 *)sc.bsph;
     int e = __builtin_amdgcn_readfirstlane(head);
     const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
     const float dlen = __builtin_sqrtf(dd);
@@ -823,7 +841,8 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     {
         e = __builtin_amdgcn_readfirstlane(e);
         QR_T(t0);
-        const qr_elem el = ld_elem(E + e);
+        const CellS cs = ld_cell(E + e);
+        const qr_elem el = cs.el;
 #ifdef QR_STATS2
         asm volatile("" :: "s"(el.simd), "s"(el.next));
         QR_T(t1); tA += t1 - t0; nA++; t0 = t1;
@@ -840,22 +859,21 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
          * bounding-volume cells or to a ray's own surface.
          */
         bool skip = false;
-        if (el.kind & 4)
+        if ((el.kind & 4) && !(sc.dbg & (SHADOW ? 64 : 128)))
         {
-            const u32x4 bs = BS[el.simd];
-            const float R = u2f(bs.w);
-            const float ocx = u2f(bs.x) - r.org.x, ocy = u2f(bs.y) - r.org.y, ocz = u2f(bs.z) - r.org.z;
+            const float R = cs.r;
+            const float ocx = cs.cx - r.org.x, ocy = cs.cy - r.org.y, ocz = cs.cz - r.org.z;
             const float b = ocx * r.dir.x + ocy * r.dir.y + ocz * r.dir.z;
             const float crx = ocy * r.dir.z - ocz * r.dir.y;
             const float cry = ocz * r.dir.x - ocx * r.dir.z;
             const float crz = ocx * r.dir.y - ocy * r.dir.x;
             const float R2 = R * R;
-            const bool outside = (ocx * ocx + ocy * ocy + ocz * ocz) > 1.01f * R2;
-            const bool miss = (crx * crx + cry * cry + crz * crz) > dd * R2
-                           || (outside && b < 0.0f)
-                           || (b - R * dlen) > w.tbuf * dd;
-            const bool need = live && w.resume == QR_NULL && !(miss && el.simd != r.osi);
-            skip = !__any(need);
+            const u32 outside = LM((ocx * ocx + ocy * ocy + ocz * ocz) > 1.01f * R2);
+            const u32 miss = LM((crx * crx + cry * cry + crz * crz) > dd * R2)
+                           | (outside & LM(b < 0.0f))
+                           | LM((b - R * dlen) > w.tbuf * dd);
+            const u32 need = LM(live && w.resume == QR_NULL) & ~(miss & LM(el.simd != r.osi));
+            skip = !__any(need != 0);
         }
 #ifdef QR_STATS2
         QR_T(t1); tB += t1 - t0; t0 = t1;
@@ -1084,7 +1102,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
     while (__any(le != QR_NULL))
     {
         const bool has = le != QR_NULL;
-        const qr_elem el = sc.elm[has ? le : 0];
+        const DCell cel = sc.elm[has ? le : 0];
+        qr_elem el; el.simd = cel.simd; el.data = cel.data; el.next = cel.next; el.kind = cel.kind;
         const qr_light *__restrict__ lg = &sc.lgt[has ? el.simd : 0];
         V3 L = {0, 0, 0};
         float dot = 0.0f;
