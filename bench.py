@@ -50,6 +50,26 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (vector), counts an FMA as 2
+
+
+def algorithmic_work(snap):
+    """fp32 operations per frame (SURVEY.md 8(d) weights), counted by the CPU oracle when the
+    fixture was made (tests/golden/make_work.py -> work.json); None if not recorded."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "work.json")) as f:
+            return json.load(f)[snap]["deferred"]
+    except Exception:
+        return None
+
+
+def measured_valu(workload):
+    """SQ counter summary of the committed rocprofv3 --pmc passes (profiles/valu.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
 
 
 def load_blob(name):
@@ -231,6 +251,14 @@ def main():
                         algorithmic_bytes_per_launch=alg_bytes,
                         note="the path is scalar-per-ray fp32 VALU work: the HBM fraction is small by construction "
                              "(4 B/pixel out + one scene read per workgroup), see DESIGN.md 'Roofline'")
+        work = algorithmic_work(snap)
+        if work is not None and work["rays"] == rays_per_frame:
+            tf = work["flops"] / (avg_ms * 1e-3) / 1e12
+            # the second, meaningful bound: fp32 vector ALU.  Algorithmic fp32 operations
+            # (div, sqrt = 1) over the kernel time against the FMA-counting vector peak; bit-exactness
+            # forbids contraction, so half of that peak is the most un-fused arithmetic can reach.
+            roofline["valu"] = dict(flops_per_launch=work["flops"], achieved=tf, peak=VALU_PEAK_TFLOPS,
+                                    unit="TFLOP/s", frac=tf / VALU_PEAK_TFLOPS, counters=measured_valu(args.workload))
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,

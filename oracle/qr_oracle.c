@@ -85,7 +85,14 @@ static inline int32_t cvt_near(float x)      /* cvnps: round half to even */
 /* state                                                                     */
 /* ------------------------------------------------------------------------ */
 
-typedef struct counts_t { uint64_t primary, shadow, reflect, refract; } counts_t;
+typedef struct counts_t { uint64_t primary, shadow, reflect, refract, flops; } counts_t;
+
+/*
+ * Algorithmic-work counter (ours, test/bench infrastructure only): fp32 operations per executed
+ * block for one lane, using the fixed weights of SURVEY.md section 8(d) (div and sqrt count 1,
+ * compares and bit operations 0).  Deterministic per (snapshot, depth, mode).
+ */
+#define FL(T, n) ((T)->cnt.flops += (uint64_t)(n))
 
 typedef struct scene_t
 {
@@ -178,6 +185,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
     float t = c->t_val;
     float x4, x5, x6;
 
+    FL(T, 15);
     /* depth testing, near plane clipping: 1602-1610 */
     m &= cgt(c->t_buf, t);
     m &= clt(c->t_min, t);
@@ -208,6 +216,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
         const int mi = ax_map(s, 0), mj = ax_map(s, 1), mk = ax_map(s, 2);
         float x0, x1, x2, x3;
         u32 hmask;
+        FL(T, 16);
         x1 = c->nw[sh + mi]; x1 = x1 * x1; x0 = x1;
         if (s->conic != 2)
         {
@@ -291,6 +300,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
                 if (redx != QR_NULL)
                 {
                     /* 1979-2004 */
+                    FL(T, 3);
                     c->nrm[3] = c->nrm[0] - k->pos[0];
                     c->nrm[4] = c->nrm[1] - k->pos[1];
                     c->nrm[5] = c->nrm[2] - k->pos[2];
@@ -311,6 +321,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
                 }
             }
             /* CC_dff: 2043-2125 */
+            FL(T, 3);
             d[0] = c->hit[0] - k->pos[0];
             d[1] = c->hit[1] - k->pos[1];
             d[2] = c->hit[2] - k->pos[2];
@@ -318,6 +329,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
             if (k->has_trm != 0)
             {
                 xform(k, d, p);
+                FL(T, 18);
                 if (k->srf_t[3] < 0)
                 {
                     c->nrm[0] = p[0]; c->nrm[1] = p[1]; c->nrm[2] = p[2];
@@ -337,6 +349,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
                     f4 = fxor(c->nrm[ksh + ax_map(k, 2)], ax_sgn(k, 2));
                     break;
                 case 2: /* QD_clp 4910-4951 */
+                    FL(T, 18);
                     f4 = c->nrm[ksh + 0]; f1 = k->scj[0]; f1 = f1 + f1; f1 = f1 * f4;
                     f4 = f4 * f4; f4 = f4 * k->sci[0]; f4 = f4 - f1;
                     f5 = c->nrm[ksh + 1]; f2 = k->scj[1]; f2 = f2 + f2; f2 = f2 * f5;
@@ -346,6 +359,7 @@ static u32 clip(tracer_t *T, ctx_t *c, int si, u32 m)
                     f4 = f4 - k->sci[3]; f4 = f4 + f5; f4 = f4 + f6;
                     break;
                 case 3: /* TP_clp 4341-4370 */
+                    FL(T, 11);
                     f4 = c->nrm[ksh + 0]; f4 = f4 * f4; f4 = f4 * k->sci[0];
                     f5 = c->nrm[ksh + 1]; f5 = f5 * f5; f5 = f5 * k->sci[1];
                     f6 = c->nrm[ksh + 2]; f6 = f6 * f6; f6 = f6 * k->sci[2];
@@ -412,6 +426,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
         return 0;
     }
 
+    FL(T, 16 + 4 + 6);      /* normal, texture lookup, ambient */
     /* surface-kind specific part: texture coords + normal */
     if (kind == NRM_PLANE)
     {
@@ -450,6 +465,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
     if ((props & QR_PROP_NORMAL) && s->has_trm != 0)
     {
         const qr_surface *tr = &v->srf[s->trnode];
+        FL(T, 24);
         x1 = c->nrm[3]; x2 = c->nrm[4]; x3 = c->nrm[5];
         x4 = tr->tci[0] * x1;
         x5 = tr->tcj[1] * x2;
@@ -531,6 +547,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
             const qr_light *lg = &v->lgt[v->elm[le].simd];
             float dot, r2;
             u32 lit;
+            FL(T, 8);
 
             x1 = lg->pos[0] - c->hit[0]; c->nw[0] = x1; x1 = x1 * c->nrm[0];
             x2 = lg->pos[1] - c->hit[1]; c->nw[1] = x2; x2 = x2 * c->nrm[1];
@@ -560,6 +577,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 if (ch.c_buf != 0) continue;        /* shadowed */
             }
             lit = 0xFFFFFFFFu;
+            FL(T, 17);
 
             x1 = c->nw[0]; x4 = x1 * x1;
             x2 = c->nw[1]; x5 = x2 * x2;
@@ -596,6 +614,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 if (props & QR_PROP_SPECULAR)
                 {
                     u32 m2;
+                    FL(T, 32);
                     x4 = x6; x5 = x6;
                     x4 = x4 * c->nrm[0]; x1 = x1 - x4; x1 = x1 - x4;
                     x5 = x5 * c->nrm[1]; x2 = x2 - x5; x2 = x2 - x5;
@@ -650,6 +669,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 if (!plain)
                 {
                     /* metal / common: 3051-3086 */
+                    FL(T, 10);
                     x1 = c->tex[0] * lg->col[0];
                     x2 = c->tex[1] * lg->col[1];
                     x3 = c->tex[2] * lg->col[2];
@@ -690,6 +710,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
             if (do_rfi)
             {
                 /* TR_rfi 3212-3324 */
+                FL(T, 65);
                 x1 = c->ray[0]; x7 = x1 * x1; x0 = x7;
                 x2 = c->ray[1]; x7 = x2 * x2; x0 = x0 + x7;
                 x3 = c->ray[2]; x7 = x3 * x3; x0 = x0 + x7;
@@ -802,6 +823,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
             (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL)))
         {
             /* RF_ini */
+            FL(T, 24);
             x1 = c->ray[0]; x4 = c->nrm[0]; x7 = x1 * x1; x0 = x7;
             x2 = c->ray[1]; x5 = c->nrm[1]; x7 = x2 * x2; x0 = x0 + x7;
             x3 = c->ray[2]; x6 = c->nrm[2]; x7 = x3 * x3; x0 = x0 + x7;
@@ -819,6 +841,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 if (props & QR_PROP_METAL)
                 {
                     /* Fresnel for metals fast: 3729-3751 */
+                    FL(T, 16);
                     x6 = mt->c_rcp;
                     x4 = x0; x4 = x4 * x6; x4 = x4 + x4;
                     x0 = x0 * x0;
@@ -838,6 +861,7 @@ static int shade(tracer_t *T, ctx_t *c, int si, int side, int kind)
                 else
                 {
                     /* RF_mtl: Fresnel for opaque plain 3765-3798 */
+                    FL(T, 16);
                     x4 = x0;
                     x6 = mt->c_rfr;
                     x0 = x0 * x6;
@@ -914,6 +938,7 @@ static int quadric_roots(tracer_t *T, ctx_t *c, int si, float a, float b, float 
 
     xmask = cle(0.0f, d) & c->wmask;
     if (xmask == 0) return 0;
+    FL(T, 10);
 
     b = fxor(b, sm);                                /* -b */
     dmask = clt(d, s->d_eps) & xmask;
@@ -1030,6 +1055,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
         if (s->srf_t[3] >= 0 && c->local_obj != QR_NULL)
         {
             /* transform caching from trnode: 1385-1417 */
+            FL(T, 3);
             if (si != c->param_obj)
             {
                 c->dff[3] = c->dff[0] - s->pos[0];
@@ -1048,6 +1074,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
                 d[0] = c->org[0] - s->pos[0];
                 d[1] = c->org[1] - s->pos[1];
                 d[2] = c->org[2] - s->pos[2];
+                FL(T, 3);
                 c->dff[0] = d[0]; c->dff[1] = d[1]; c->dff[2] = d[2];
                 if (s->has_trm == 0)
                 {
@@ -1056,6 +1083,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
                 else
                 {
                     xform(s, d, p);
+                    FL(T, s->has_trm == 1 ? 3 : 15);
                     if (s->srf_t[3] < 0)
                     {
                         c->dff[0] = p[0]; c->dff[1] = p[1]; c->dff[2] = p[2];
@@ -1070,6 +1098,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
             if (do_ray)
             {
                 xform(s, &c->ray[0], &c->ray[3]);   /* OO_ray 1508-1554 */
+                FL(T, s->has_trm == 1 ? 3 : 15);
             }
         }
 
@@ -1078,6 +1107,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
         {
             /* AR_ptr: bounding volume 3955-4054 */
             float x0, x1, x2, x3, x4, x5, x6, x7;
+            FL(T, 25);
             x1 = c->ray[sh + 0]; x0 = s->sci[0] * x1; x5 = c->dff[sh + 0]; x7 = s->sci[0] * x5;
             x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
             x2 = c->ray[sh + 1]; x0 = s->sci[1] * x2; x6 = c->dff[sh + 1]; x7 = s->sci[1] * x6;
@@ -1111,6 +1141,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
                 float dk = fxor(c->dff[sh + mk], sg);
                 float rk = fxor(c->ray[sh + mk], sg);
                 u32 m;
+                FL(T, 1);
                 dk = fxor(dk, s->smask);
                 m = cne(0.0f, rk) & c->wmask;
                 c->t_val = dk / rk;
@@ -1127,6 +1158,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
         {
             /* QD_ptr 4378-4447 */
             float x0, x1, x2, x3, x4, x5, x6, x7;
+            FL(T, 31);
             x1 = c->ray[sh + 0]; x0 = s->sci[0] * x1; x5 = c->dff[sh + 0]; x7 = s->sci[0] * x5;
             x7 = x7 - s->scj[0]; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s->scj[0]; x5 = x5 * x7;
             x2 = c->ray[sh + 1]; x0 = s->sci[1] * x2; x6 = c->dff[sh + 1]; x7 = s->sci[1] * x6;
@@ -1144,6 +1176,7 @@ static void trace_list(tracer_t *T, ctx_t *c, const float *parent_loc, int head)
             /* TP_ptr 4216-4277 */
             const int mi = ax_map(s, 0), mk = ax_map(s, 2);
             float x0, x1, x2, x3, x4, x5, x6, x7;
+            FL(T, 21);
             x1 = c->ray[sh + mi]; x5 = c->dff[sh + mi]; x3 = s->sci[mi];
             x2 = c->ray[sh + mk]; x6 = c->dff[sh + mk]; x4 = s->sci[mk];
             x0 = x5; x7 = x6;
@@ -1205,6 +1238,7 @@ static void sample(tracer_t *T, int x, int y, int k, float col[3], int *hit_id)
     c.hit_id = -1;
 
     /* primary ray 1287-1322 */
+    FL(T, 16);
     hs = (float)x + fr->hor_a[ai]; hs = hs + 0.0f;
     vs = (float)y + fr->ver_a[ai]; vs = vs + 0.0f;
     x1 = fr->hor[0] * hs; x2 = fr->hor[1] * hs; x3 = fr->hor[2] * hs;
@@ -1239,6 +1273,7 @@ static u32 pixel(tracer_t *T, int x, int y, int *hit_id)
         if (k == 0) id = h;
         for (ch = 0; ch < 3; ch++) s[k][ch] = clamp1(s[k][ch]);
     }
+    FL(T, 6 + 2 * fr->fsaa);
     /* AA_cyc 5241-5308: per pass halve, then add neighbours */
     for (ch = 0; ch < 3; ch++)
     {
@@ -1276,6 +1311,11 @@ static u32 pixel(tracer_t *T, int x, int y, int *hit_id)
  * deferred != 0: shade only the final hit of each list walk (same pixels, fewer
  * rays: the "useful ray" count the HIP backend also reports).
  */
+static uint64_t g_last_flops;
+
+/* fp32 operation count (SURVEY.md 8(d) weights) of the most recent qro_render/qro_render2 call */
+uint64_t qro_last_flops(void) { return g_last_flops; }
+
 int qro_render2(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
                 int depth, int row_begin, int row_end, int index, int thnum,
                 int threads, uint64_t counts[4], int deferred)
@@ -1283,7 +1323,7 @@ int qro_render2(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
     scene_t S;
     int rc = qr_scene_view_init(&S.v, blob, size);
     int y, w, h;
-    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     if (rc != 0) return rc;
     S.depth = depth >= 0 ? depth : S.v.frame->depth;
     w = S.v.frame->frm_w; h = S.v.frame->frm_h;
@@ -1294,7 +1334,7 @@ int qro_render2(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
-#pragma omp parallel for schedule(dynamic, 4) reduction(+:c0,c1,c2,c3)
+#pragma omp parallel for schedule(dynamic, 4) reduction(+:c0,c1,c2,c3,c4)
     for (y = row_begin; y < row_end; y++)
     {
         tracer_t T;
@@ -1309,8 +1349,9 @@ int qro_render2(const void *blob, uint64_t size, uint32_t *frame, int32_t *ids,
             frame[(size_t)y * w + x] = p;
             if (ids) ids[(size_t)y * w + x] = id;
         }
-        c0 += T.cnt.primary; c1 += T.cnt.shadow; c2 += T.cnt.reflect; c3 += T.cnt.refract;
+        c0 += T.cnt.primary; c1 += T.cnt.shadow; c2 += T.cnt.reflect; c3 += T.cnt.refract; c4 += T.cnt.flops;
     }
+    g_last_flops = c4;
     if (counts) { counts[0] = c0; counts[1] = c1; counts[2] = c2; counts[3] = c3; }
     return 0;
 }

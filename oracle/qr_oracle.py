@@ -22,6 +22,7 @@ def lib():
         L.qro_render.restype = ctypes.c_int
         L.qro_render2.argtypes = L.qro_render.argtypes + [ctypes.c_int]
         L.qro_render2.restype = ctypes.c_int
+        L.qro_last_flops.restype = ctypes.c_uint64
         L.qro_info.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.qro_info.restype = ctypes.c_int
         L.qro_hash.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
@@ -54,7 +55,8 @@ def render(blob, depth=-1, threads=0, want_ids=False, rows=None, index=0, thnum=
                            depth, r0, r1, index, thnum, threads, counts, 1 if deferred else 0)
     if rc != 0:
         raise RuntimeError(f"qro_render rc={rc}")
-    return frame, ids, dict(primary=counts[0], shadow=counts[1], reflect=counts[2], refract=counts[3])
+    return frame, ids, dict(primary=counts[0], shadow=counts[1], reflect=counts[2], refract=counts[3],
+                            flops=int(lib().qro_last_flops()))
 
 
 def frame_hash(frame):

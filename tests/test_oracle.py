@@ -57,3 +57,21 @@ def test_deferred_shading_is_pixel_identical(oracle, name):
     assert (eager == lazy).all() and (ids_e == ids_l).all()
     assert c_l["primary"] == c_e["primary"]
     assert all(c_l[k] <= c_e[k] for k in c_e)
+
+
+def test_work_counter_is_deterministic_and_matches_committed_table(oracle):
+    """The fp32-operation counter behind bench.py's VALU roofline (SURVEY.md 8(d) weights): independent
+    of the thread count, smaller in deferred mode, and equal to tests/golden/work.json at full size."""
+    import json, os
+    blob = load_blob("demo02_160_gf_aa4")
+    _, _, a = oracle.render(blob, threads=1)
+    _, _, b = oracle.render(blob, threads=4)
+    _, _, d = oracle.render(blob, threads=4, deferred=True)
+    assert a == b and a["flops"] > 0
+    assert 0 < d["flops"] <= a["flops"]
+    work = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "work.json")))
+    blob = load_blob("c2_demo01_1080p_d0")
+    _, _, c = oracle.render(blob, threads=8, deferred=True)
+    w = work["c2_demo01_1080p_d0"]["deferred"]
+    assert c["flops"] == w["flops"]
+    assert c["primary"] + c["shadow"] + c["reflect"] + c["refract"] == w["rays"]
