@@ -438,7 +438,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
-    e = hipMalloc((void **)&s->d_counters, 16 * sizeof(unsigned long long));
+    e = hipMalloc((void **)&s->d_counters, 32 * sizeof(unsigned long long));
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     (void)hipEventCreate(&s->ev0);
     (void)hipEventCreate(&s->ev1);
@@ -566,7 +566,7 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     if (s == nullptr || frame_dev == nullptr || counts == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), st));
     HIP_TRY(launch<true>(s, frame_dev, nullptr, st));
     unsigned long long h[4];
     HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -584,12 +584,13 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
 #endif
 #ifdef QR_STATS
     {
-        unsigned long long st[12];
+        unsigned long long st[16];
         HIP_TRY(hipMemcpy(st, s->d_counters + 4, sizeof(st), hipMemcpyDeviceToHost));
         const char *nm[3] = { "shadow", "primary", "secondary" };
         for (int k = 0; k < 3; k++)
-            fprintf(stderr, "QR_STATS %s: walks %llu elem-iterations %llu (%.1f per walk) active lanes per iteration %.1f\n", nm[k],
+            fprintf(stderr, "QR_STATS %s: walks %llu elem-iterations %llu (%.1f per walk, %.0f%% culled) active lanes per iteration %.1f\n", nm[k],
                     st[3 * k], st[3 * k + 1], st[3 * k] ? (double)st[3 * k + 1] / st[3 * k] : 0.0,
+                    st[3 * k + 1] ? 100.0 * st[12 + k] / st[3 * k + 1] : 0.0,
                     st[3 * k + 1] ? (double)st[3 * k + 2] / st[3 * k + 1] : 0.0);
         fprintf(stderr, "QR_STATS wave-cycles (s_memtime): primary/secondary traverse %llu, shade incl. shadow walks %llu, rest %llu\n", st[9], st[10], st[11]);
     }

@@ -828,7 +828,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
     const float dlen = __builtin_sqrtf(dd);
 #ifdef QR_STATS
-    unsigned long long st_iter = 0, st_lanes = 0;
+    unsigned long long st_iter = 0, st_lanes = 0, st_skip = 0;
 #endif
 #ifdef QR_STATS2
     unsigned long long tA = 0, tB = 0, tC = 0, nA = 0, nC = 0, t0, t1;
@@ -881,7 +881,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         if (skip)
         {
 #ifdef QR_STATS
-            st_lanes += 1000000ull;
+            st_skip++;
 #endif
             if (e == w.local_obj) w.local_obj = QR_NULL;
             if (w.resume == e) w.resume = QR_NULL;
@@ -915,6 +915,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         atomicAdd(&sc.stats[b + 0], 1ull);
         atomicAdd(&sc.stats[b + 1], st_iter);
         atomicAdd(&sc.stats[b + 2], st_lanes);
+        atomicAdd(&sc.stats[12 + b / 3], st_skip);
     }
 #endif
 }
