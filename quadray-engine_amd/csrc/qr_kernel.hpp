@@ -840,6 +840,25 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
+        /*
+         * No ray of the group is outside a bounding-volume skip: the reference jumps a whole packet
+         * to the end of an array whose volume no lane hits (tracer.cpp:4040-4054); here rays skip
+         * individually, so take the jump when all live rays wait for the same element, else step.
+         */
+        if (__ballot(live && w.resume == QR_NULL) == 0)
+        {
+            const unsigned long long lv = __ballot(live);
+            const int T = __builtin_amdgcn_readlane(w.resume, lv ? __ffsll((long long)lv) - 1 : 0);
+            if (lv != 0 && __ballot(live && w.resume != T) == 0) e = T;
+            const qr_elem sk = ld_elem(E + e);
+            if (e == w.local_obj) w.local_obj = QR_NULL;
+            if (w.resume == e) w.resume = QR_NULL;
+            e = sk.next;
+#ifdef QR_STATS
+            st_iter++; st_skip++;
+#endif
+            continue;
+        }
         QR_T(t0);
         const CellS cs = ld_cell(E + e);
         const qr_elem el = cs.el;
