@@ -547,8 +547,8 @@ __device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
 /* ------------------------------------------------------------------------ */
 
 template <bool SHADOW>
-__device__ __forceinline__ void walk_element(const DevScene &sc, const int e, const qr_elem &el, SrfP P,
-                                             const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live
+__device__ __forceinline__ int walk_element(const DevScene &sc, const int e, const qr_elem &el, SrfP P,
+                                            const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live
 #ifdef QR_STATS2
                                              , unsigned long long *g_seg
 #endif
@@ -807,6 +807,13 @@ __device__ __forceinline__ void walk_element(const DevScene &sc, const int e, co
     { unsigned long long t_; QR_TT(t_); g_seg[3] += t_ - g_t; g_t = t_; }
 #endif
     if (w.resume == e) w.resume = QR_NULL;
+    /*
+     * The reference jumps a whole packet to the end of an array whose bounding volume no lane hits
+     * (tracer.cpp:4040-4054); here rays skip individually, so take the jump when this array head
+     * left every live ray of the group waiting for its last element.
+     */
+    if ((el.kind & 3) == 1 && !__any(live && w.resume != el.data)) return el.data;
+    return QR_NULL;
 }
 
 /*
@@ -840,25 +847,6 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
-        /*
-         * No ray of the group is outside a bounding-volume skip: the reference jumps a whole packet
-         * to the end of an array whose volume no lane hits (tracer.cpp:4040-4054); here rays skip
-         * individually, so take the jump when all live rays wait for the same element, else step.
-         */
-        if (__ballot(live && w.resume == QR_NULL) == 0)
-        {
-            const unsigned long long lv = __ballot(live);
-            const int T = __builtin_amdgcn_readlane(w.resume, lv ? __ffsll((long long)lv) - 1 : 0);
-            if (lv != 0 && __ballot(live && w.resume != T) == 0) e = T;
-            const qr_elem sk = ld_elem(E + e);
-            if (e == w.local_obj) w.local_obj = QR_NULL;
-            if (w.resume == e) w.resume = QR_NULL;
-            e = sk.next;
-#ifdef QR_STATS
-            st_iter++; st_skip++;
-#endif
-            continue;
-        }
         QR_T(t0);
         const CellS cs = ld_cell(E + e);
         const qr_elem el = cs.el;
@@ -878,6 +866,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
          * bounding-volume cells or to a ray's own surface.
          */
         bool skip = false;
+        int jump = QR_NULL;
         if ((el.kind & 4) && !(sc.dbg & (SHADOW ? 64 : 128)))
         {
             const float R = cs.r;
@@ -907,7 +896,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         }
         else
         {
-            walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live
+            jump = walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live
 #ifdef QR_STATS2
                                  , seg
 #endif
@@ -917,7 +906,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
 #endif
         }
         if (SHADOW && !__any(live)) break;
-        e = el.next;
+        e = jump != QR_NULL ? jump : el.next;
     }
 #ifdef QR_STATS2
     if (SHADOW && __ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
@@ -992,6 +981,9 @@ struct Shaded
 };
 
 struct Counters { u32 primary, shadow, reflect, refract; };
+
+/* state of the enclosing recursion that only has to survive a shade() call */
+struct Outer { V3 ret; int hit_id, sp, mode; };
 
 template <bool COUNT>
 __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r, const Hit &h,
@@ -1145,7 +1137,13 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         if (COUNT) { if (lm) cnt.shadow++; }
         if (sc.dbg & 2) lm = false;
         if (sc.dbg & 1) occ = false; else
-        traverse<true>(sc, lm, sr, sh, occ);
+        {
+#ifdef QR_X_NOSHADOW
+            occ = false; sh.si = 0;
+#else
+            traverse<true>(sc, lm, sr, sh, occ);
+#endif
+        }
         if (lm && !occ)
         {
             const qr_material *__restrict__ mt = &sc.mat[mi];
@@ -1479,10 +1477,13 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
 #else
 #define QR_TICK(acc) do { } while (0)
 #endif
-    int sp = 0;
-    int mode = inside ? 0 : 2;                  /* 0 trace, 1 return, 2 done */
-    V3 ret = {0, 0, 0};
-    int hit_id = -1;
+    Outer ou;
+    ou.sp = 0;
+    ou.mode = inside ? 0 : 2;                   /* 0 trace, 1 return, 2 done */
+    ou.ret = {0, 0, 0};
+    ou.hit_id = -1;
+    int &sp = ou.sp, &mode = ou.mode, &hit_id = ou.hit_id;
+    V3 &ret = ou.ret;
     const int depth = sc.depth;
 
     if (COUNT && inside) cnt.primary++;
@@ -1494,7 +1495,11 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         {
             Hit h; bool occ;
             QR_TICK(tk_rest);
+#ifdef QR_X_NOTRACE
+            h.t = ray.tmax; h.si = ray.list; h.side = 0; h.loc = ray.ploc; occ = false;
+#else
             traverse<false>(sc, tr, ray, h, occ);
+#endif
             QR_TICK(tk_trav);
             const bool got = tr && h.si != QR_NULL && !(sc.dbg & 4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
