@@ -322,7 +322,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     {
         std::vector<uint8_t> seen(n_elm + 1, 0);
         const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
-        const int cull_mode = getenv("QR_NOCULL") ? 0 : (cm ? atoi(cm) : 2);
+        const int cull_mode = getenv("QR_NOCULL") ? 0 : (cm ? atoi(cm) : 3);
         auto mark_list = [&](int head) {
             for (int e = head; e != QR_NULL && !seen[e]; e = v.elm[e].next)
             {
