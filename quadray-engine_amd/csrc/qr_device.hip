@@ -353,18 +353,21 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     /* wave schedule: one entry per wave footprint (8x8 / 8x4 / 4x4 pixels) */
     const int fw = fr.fsaa == 2 ? 4 : 8, fh = fr.fsaa == 0 ? 8 : 4;
     const int nbx = (fr.frm_w + fw - 1) / fw, nby = (fr.frm_h + fh - 1) / fh;
-    if (nbx > 0xFFFF || nby > 0xFFFF) return qr_fail(QR_ERR_ARG, "frame too large");
+    if (nbx > 0x3FFF || nby > 0x3FFF) return qr_fail(QR_ERR_ARG, "frame too large");
     std::vector<uint32_t> order;
     {
         /* heavy = the footprint's tile list holds a reflective or non-opaque surface */
         std::vector<uint8_t> tile_heavy((size_t)fr.tls_row * fr.tls_col, 0);
         for (size_t t = 0; t < tile_heavy.size(); t++)
-            for (int e = v.tiles[t]; e != QR_NULL && !tile_heavy[t]; e = v.elm[e].next)
+            for (int e = v.tiles[t]; e != QR_NULL; e = v.elm[e].next)
             {
                 const qr_surface &q = v.srf[v.elm[e].simd];
                 if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
                 for (int k = 0; k < 2; k++)
-                    if ((q.props[k] & QR_PROP_REFLECT) || !(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] = 1;
+                {
+                    if (q.props[k] & QR_PROP_REFLECT) tile_heavy[t] |= 1;
+                    if (!(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] |= 2;
+                }
             }
         std::vector<uint32_t> heavy, light;
         /* enumerate footprints tile by tile (32x8 pixel groups) to keep neighbours together */
@@ -377,8 +380,9 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                         const int bx = tx * gx + i, by = ty * gy + j;
                         if (bx >= nbx || by >= nby) continue;
                         const int tlx = (bx * fw) / fr.tile_w, tly = (by * fh) / fr.tile_h;
-                        const bool hv = tlx < fr.tls_row && tly < fr.tls_col && tile_heavy[(size_t)tly * fr.tls_row + tlx];
-                        (hv ? heavy : light).push_back((uint32_t)bx | ((uint32_t)by << 16));
+                        const int hv = (tlx < fr.tls_row && tly < fr.tls_col) ? tile_heavy[(size_t)tly * fr.tls_row + tlx] : 0;
+                        const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14);
+                        (hv ? heavy : light).push_back(ent);
                     }
         order = heavy;
         order.insert(order.end(), light.begin(), light.end());
@@ -438,7 +442,11 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+#ifdef QR_WAVETIME
+    e = hipMalloc((void **)&s->d_counters, (32 + 4 * order.size()) * sizeof(unsigned long long));
+#else
     e = hipMalloc((void **)&s->d_counters, 32 * sizeof(unsigned long long));
+#endif
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     (void)hipEventCreate(&s->ev0);
     (void)hipEventCreate(&s->ev1);
@@ -617,6 +625,16 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     }
     if (avg_ms) *avg_ms = (float)(sum / iters);
     if (min_ms) *min_ms = mn;
+#ifdef QR_WAVETIME
+    if (const char *path = getenv("QR_WAVETIME_OUT"))
+    {
+        /* per wave of the last launch: {start, first traverse done, end} in 100 MHz ticks, {hw_id | xcc << 32 | walks << 40} */
+        std::vector<unsigned long long> w((size_t)s->sc.n_blocks * 4);
+        HIP_TRY(hipMemcpy(w.data(), s->d_counters + 32, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        FILE *f = fopen(path, "wb");
+        if (f) { fwrite(w.data(), sizeof(unsigned long long), w.size(), f); fclose(f); }
+    }
+#endif
     return QR_OK;
 }
 

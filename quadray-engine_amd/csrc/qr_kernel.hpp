@@ -122,7 +122,7 @@ struct DevScene
     int32_t index, thnum;         /* reference row interleave                */
     int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
     const void        *__restrict__ bsph;   /* float4 per surface: world-space bounding sphere (cx,cy,cz,r) */
-    const uint32_t    *__restrict__ order;  /* block schedule: bx | by << 16, heavy tiles first */
+    const uint32_t    *__restrict__ order;  /* wave schedule: bx | by << 14, heavy footprints first */
     int32_t n_blocks;
     unsigned long long *stats;    /* QR_STATS builds only: walk statistics */
     int32_t dbg;                  /* timing experiments only (QR_DBG): 1 no shadow walks, 2 no lights */
@@ -1416,6 +1416,10 @@ __global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                       unsigned long long *__restrict__ counters)
 {
+#ifdef QR_WAVETIME
+    const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_mid = 0; u32 wt_push = 0;
+#endif
     const FrmP fr = c_frm(sc);
     const int fsaa = fr->fsaa;
     const int ns = 1 << fsaa;
@@ -1433,8 +1437,9 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     const int gw = (int)blockIdx.x * (QR_BLOCK / 64) + wv;
     if (gw >= sc.n_blocks) return;
     const u32 ord = sc.order[gw];
-    const int x = (int)(ord & 0xFFFFu) * fw + (fsaa == 2 ? (pix & 3) : (pix & 7));
-    const int y = (int)(ord >> 16) * fh + (fsaa == 2 ? (pix >> 2) : (pix >> 3));
+    const int px = fsaa == 2 ? (pix & 3) : (pix & 7), py = fsaa == 2 ? (pix >> 2) : (pix >> 3);
+    const int x = (int)(ord & 0x3FFFu) * fw + px;
+    const int y = (int)((ord >> 14) & 0x3FFFu) * fh + py;
     const int group = y >> 3;
 
     bool inside = x < fr->frm_w && y < fr->frm_h && y >= sc.row_begin && y < sc.row_end;
@@ -1501,6 +1506,10 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
             traverse<false>(sc, tr, ray, h, occ);
 #endif
             QR_TICK(tk_trav);
+#ifdef QR_WAVETIME
+            if (wt_mid == 0) wt_mid = __builtin_amdgcn_s_memrealtime();
+            wt_push++;
+#endif
             const bool got = tr && h.si != QR_NULL && !(sc.dbg & 4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
             if (got && sp == 0) hit_id = (h.si << 1) | h.side;
@@ -1618,6 +1627,16 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     if (lane == 0)
     {
         atomicAdd(&sc.stats[9], tk_trav); atomicAdd(&sc.stats[10], tk_shade); atomicAdd(&sc.stats[11], tk_rest);
+    }
+#endif
+#ifdef QR_WAVETIME
+    if (!COUNT && __ffsll((long long)__ballot(true)) - 1 == lane)
+    {
+        unsigned long long *o = counters + 32 + (size_t)gw * 4;
+        o[0] = wt_start; o[1] = wt_mid; o[2] = __builtin_amdgcn_s_memrealtime();
+        o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))
+             | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 32)
+             | ((unsigned long long)wt_push << 40);
     }
 #endif
     /* XX_end 5161-5343: clamp, FSAA reduce, gamma, pack */

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one launch (QR_WAVETIME build): tools/gpu_wavetime.py NAME [depth] (GPU box).
+Build first: make -C quadray-engine_amd/csrc variant NAME=wt EXTRA=-DQR_WAVETIME"""
+import os, sys, gzip
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["QR_LIB"] = os.path.join(ROOT, "quadray-engine_amd", "libqrhip_wt.so")
+out = os.path.join(ROOT, "gpurun_out", f"wavetime_{sys.argv[1]}.bin")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ["QR_WAVETIME_OUT"] = out
+sys.path.insert(0, ROOT)
+import torch
+from qr_loader import load_package
+qr = load_package()
+blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", sys.argv[1] + ".qrs.gz"), "rb").read())
+scn = qr.Scene(blob)
+if len(sys.argv) > 2:
+    scn.set_depth(int(sys.argv[2]))
+f = scn.new_frame()
+scn.render(f); torch.cuda.synchronize()
+avg, mn = scn.render_timed(f, 5)
+w = np.fromfile(out, dtype=np.uint64).reshape(-1, 4)
+w = w[w[:, 2] != 0]
+t0 = int(w[:, 0].min())
+st = (w[:, 0].astype(np.int64) - t0) / 100.0          # us
+mid = (w[:, 1].astype(np.int64) - t0) / 100.0
+en = (w[:, 2].astype(np.int64) - t0) / 100.0
+dur = en - st
+walks = (w[:, 3] >> np.uint64(40)).astype(np.int64)
+print(f"{sys.argv[1]}: kernel {avg*1e3:.1f} us; waves {len(w)}; last wave ends at {en.max():.1f} us")
+print("wave duration us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(dur, [10, 50, 90, 99, 100])))
+print("first traverse (start->after) us: p50 %.1f p90 %.1f" % tuple(np.percentile(mid - st, [50, 90])))
+print("non-shadow walks per wave: mean %.2f max %d; waves with >1: %d" % (walks.mean(), walks.max(), (walks > 1).sum()))
+for lo, hi in [(1, 1), (2, 3), (4, 8), (9, 1000)]:
+    m = (walks >= lo) & (walks <= hi)
+    if m.any():
+        print(f"  walks {lo}-{hi}: {m.sum()} waves, duration mean {dur[m].mean():.1f} us max {dur[m].max():.1f}, start p50 {np.median(st[m]):.1f}, end max {en[m].max():.1f}")
+# occupancy over time: waves in flight sampled every 5% of the kernel
+T = en.max()
+for q in np.linspace(0.05, 1.0, 20):
+    t = q * T
+    print(f"  t={t:7.1f} us in flight {int(((st <= t) & (en > t)).sum())}", end="")
+print()
