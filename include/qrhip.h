@@ -104,6 +104,19 @@ typedef struct qr_ray_counts
 
 /* Upload a snapshot blob to `device` (HIP ordinal). */
 int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene **out);
+
+/*
+ * As qr_scene_upload with options.  QR_UPLOAD_REBIN_TILES discards the snapshot's per-tile
+ * surface lists and rebuilds them on the GPU from the camera list `clist` (replaces the tile
+ * binning of rt_Scene::render / render_slice, engine.cpp:1956-2128, 3129-3253): every surface's
+ * conservative screen rectangle is matched against every tile by a binning kernel that keeps the
+ * camera list's order and its trnode markers.  Tile lists only cull, so frames are unchanged.
+ * Needed for snapshots that carry no tile lists (tiling off, synthetic scenes).  The tile size is
+ * the snapshot's unless it has a single tile, then 32x8 (engine.h:38-39).
+ * Setting the environment variable QR_REBIN=1 turns the flag on for every upload.
+ */
+#define QR_UPLOAD_REBIN_TILES 1u
+int qr_scene_upload_ex(const void *blob, uint64_t size, int device, uint32_t flags, qr_device_scene **out);
 int qr_scene_destroy(qr_device_scene *scn);
 int qr_scene_get_info(const qr_device_scene *scn, qr_scene_info *info);
 

@@ -18,11 +18,14 @@ LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR
 # every symbol include/qrhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
-    "qr_scene_upload", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
+    "qr_scene_upload", "qr_scene_upload_ex", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
     "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
 ]
+
+
+UPLOAD_REBIN_TILES = 1
 
 
 class QrError(RuntimeError):
@@ -72,6 +75,7 @@ def lib():
     L.qr_kernel_name.restype = ctypes.c_char_p
     L.qr_device_count.restype = ci
     L.qr_scene_upload.argtypes = [vp, cu64, ci, ctypes.POINTER(vp)]
+    L.qr_scene_upload_ex.argtypes = [vp, cu64, ci, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.qr_scene_destroy.argtypes = [vp]
     L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
     L.qr_scene_set_depth.argtypes = [vp, ci]
@@ -101,10 +105,13 @@ def read_snapshot(path):
 class Scene:
     """A snapshot resident on one GPU (qr_device_scene)."""
 
-    def __init__(self, blob, device=0):
+    def __init__(self, blob, device=0, rebin_tiles=False):
+        """rebin_tiles: rebuild the per-tile lists on the GPU from the camera list
+        (QR_UPLOAD_REBIN_TILES, include/qrhip.h) instead of using the snapshot's."""
         self._h = ctypes.c_void_p()
         self._buf = ctypes.create_string_buffer(blob, len(blob))
-        _check(lib().qr_scene_upload(self._buf, len(blob), device, ctypes.byref(self._h)))
+        _check(lib().qr_scene_upload_ex(self._buf, len(blob), device, UPLOAD_REBIN_TILES if rebin_tiles else 0,
+                                        ctypes.byref(self._h)))
         self.device = device
         self.info = SceneInfo()
         _check(lib().qr_scene_get_info(self._h, ctypes.byref(self.info)))

@@ -33,6 +33,7 @@ struct qr_device_scene
     qr_frame fr;                /* host copy of the frame parameters        */
     qr_header hdr;
     unsigned long long *d_counters;
+    size_t n_cells;
     hipEvent_t ev0, ev1;
 };
 
@@ -56,9 +57,11 @@ static size_t pad16(size_t x) { return (x + 15) & ~(size_t)15; }
  * in the reference's hit points cannot turn a real hit into a cull.
  */
 struct BSphere { float c[3]; float r; };
+struct BBox { bool valid; double p[8][3]; };     /* world-space corners of the (oriented) bounding box */
 
-static BSphere bound_sphere(const qr_scene_view &v, int i)
+static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
 {
+    if (box) box->valid = false;
     const double INF = 1e300;
     BSphere out = { {0.0f, 0.0f, 0.0f}, __builtin_inff() };
     const qr_surface &q = v.srf[i];
@@ -127,6 +130,12 @@ static BSphere bound_sphere(const qr_scene_view &v, int i)
     if (q.has_trm == 0)
     {
         for (int k = 0; k < 3; k++) cw[k] = (double)q.pos[k] + cl[k];
+        if (box)
+        {
+            for (int c = 0; c < 8; c++)
+                for (int k = 0; k < 3; k++) box->p[c][k] = (double)q.pos[k] + (((c >> k) & 1) ? hi[k] : lo[k]);
+            box->valid = true;
+        }
     }
     else
     {
@@ -157,6 +166,18 @@ static BSphere bound_sphere(const qr_scene_view &v, int i)
             for (int b = 0; b < 3; b++) { cw[a] += inv[a][b] * pl[b]; fro += inv[a][b] * inv[a][b]; }
         }
         rl *= __builtin_sqrt(fro);
+        if (box)
+        {
+            for (int c = 0; c < 8; c++)
+                for (int a = 0; a < 3; a++)
+                {
+                    double acc = (double)t.pos[a];
+                    for (int b = 0; b < 3; b++)
+                        acc += inv[a][b] * ((((c >> b) & 1) ? hi[b] : lo[b]) + (q.trnode == i ? 0.0 : (double)q.pos[b]));
+                    box->p[c][a] = acc;
+                }
+            box->valid = true;
+        }
     }
     const double r = rl * 1.002 + 2e-3;
     if (!(r < 1e30)) return out;
@@ -165,9 +186,270 @@ static BSphere bound_sphere(const qr_scene_view &v, int i)
     return out;
 }
 
+/* ------------------------------------------------------------------------ */
+/* GPU tile binning (replaces the reference's host tiling, engine.cpp:1956-2128, 3129-3253)     */
+/* ------------------------------------------------------------------------ */
+
+struct BinEntry
+{
+    int32_t simd;           /* surface index                                              */
+    int32_t marker;         /* 1: trnode marker of an array, 0: surface                   */
+    int32_t end;            /* marker: index of the last entry of its sub-list            */
+    int32_t data;           /* surface: the camera-list cell's data field                 */
+    int32_t x0, y0, x1, y1; /* surface: inclusive tile rectangle, x1 < x0 = off screen    */
+};
+
+#define QR_BIN_DEPTH 4      /* nesting of transformed arrays the binning kernel tracks    */
+
+/*
+ * One thread per tile walks the camera list's entries in order (entry loads are wave-uniform) and
+ * emits the cells of the surfaces whose rectangle covers the tile; a trnode marker is emitted in
+ * front of the first covered member of its array and its data field is patched to the last one,
+ * exactly the structure of the engine's tile lists.  FILL = false only counts.
+ */
+template <bool FILL>
+__global__ void qr_bin_kernel(const BinEntry *__restrict__ ent, int n_ent, int tls_row, int n_tiles,
+                              int32_t *__restrict__ count, const int32_t *__restrict__ offset,
+                              qr_elem *__restrict__ cells, int32_t *__restrict__ heads, int cell_base)
+{
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n_tiles) return;
+    const int tx = t % tls_row, ty = t / tls_row;
+    const int base = FILL ? offset[t] : 0;
+    int n = 0, prev = -1, sd = 0;
+    int m_ent[QR_BIN_DEPTH], m_slot[QR_BIN_DEPTH], m_last[QR_BIN_DEPTH];
+#pragma unroll
+    for (int d = 0; d < QR_BIN_DEPTH; d++) { m_ent[d] = -1; m_slot[d] = -1; m_last[d] = -1; }
+
+    for (int k = 0; k <= n_ent; k++)
+    {
+        /* close the arrays that ended before entry k */
+#pragma unroll
+        for (int d = QR_BIN_DEPTH - 1; d >= 0; d--)
+            if (d < sd && (k == n_ent || k > ent[m_ent[d]].end))
+            {
+                if (FILL && m_slot[d] >= 0) cells[m_slot[d]].data = cell_base + m_last[d];
+                m_slot[d] = -1; sd = d;
+            }
+        if (k == n_ent) break;
+        const BinEntry e = ent[k];
+        if (e.marker)
+        {
+#pragma unroll
+            for (int d = 0; d < QR_BIN_DEPTH; d++) if (d == sd) { m_ent[d] = k; m_slot[d] = -1; m_last[d] = -1; }
+            sd++;
+            continue;
+        }
+        if (tx < e.x0 || tx > e.x1 || ty < e.y0 || ty > e.y1) continue;
+#pragma unroll
+        for (int d = 0; d < QR_BIN_DEPTH; d++)
+            if (d < sd && m_slot[d] < 0)
+            {
+                const int slot = base + n;
+                if (FILL)
+                {
+                    qr_elem c; c.simd = ent[m_ent[d]].simd; c.data = QR_NULL; c.next = QR_NULL; c.kind = 0;
+                    cells[slot] = c;
+                    if (prev >= 0) cells[prev].next = cell_base + slot;
+                }
+                m_slot[d] = slot; prev = slot; n++;
+            }
+        {
+            const int slot = base + n;
+            if (FILL)
+            {
+                qr_elem c; c.simd = e.simd; c.data = e.data; c.next = QR_NULL; c.kind = 0;
+                cells[slot] = c;
+                if (prev >= 0) cells[prev].next = cell_base + slot;
+            }
+            prev = slot; n++;
+#pragma unroll
+            for (int d = 0; d < QR_BIN_DEPTH; d++) if (d < sd) m_last[d] = slot;
+        }
+    }
+    if (FILL) heads[t] = n ? cell_base + base : QR_NULL;
+    else count[t] = n;
+}
+
+/* conservative inclusive pixel interval [lo, hi] in which a primary ray can meet the disc that a
+ * sphere projects to in the plane spanned by one image axis and the view axis; false = never */
+static bool screen_interval(double a, double z, double R, double c_pix, double pov_over_step, double *lo, double *hi)
+{
+    const double HALF_PI = 1.5707963267948966;
+    const double rho = __builtin_sqrt(a * a + z * z);
+    *lo = -1e300; *hi = 1e300;
+    if (!(rho > R * 1.001 + 1e-9)) return true;                 /* the eye is inside the disc */
+    const double th = __builtin_atan2(a, z), al = __builtin_asin(R / rho) + 1e-6;
+    const double l = th - al, h = th + al;
+    if (l >= HALF_PI - 1e-6 || h <= -HALF_PI + 1e-6) return false;    /* entirely behind the image plane */
+    if (l > -HALF_PI + 1e-6) *lo = c_pix + pov_over_step * __builtin_tan(l);
+    if (h < HALF_PI - 1e-6) *hi = c_pix + pov_over_step * __builtin_tan(h);
+    return true;
+}
+
+/*
+ * Build tile lists for `frm` on the GPU from the camera list.  Appends the new cells to E and
+ * fills T (frm.tls_row * frm.tls_col heads).
+ */
+static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph, qr_frame &frm,
+                       std::vector<qr_elem> &E, std::vector<int32_t> &T)
+{
+    if ((int)v.hdr->n_tiles <= 1)
+    {
+        frm.tile_w = 32; frm.tile_h = 8;                        /* RT_TILE_W, RT_TILE_H: engine.h:38-39 */
+        if (const char *ts = getenv("QR_BIN_TILE")) { int w = 0, h = 0; if (sscanf(ts, "%dx%d", &w, &h) == 2 && w > 0 && h > 0) { frm.tile_w = w; frm.tile_h = h; } }
+    }
+    frm.tls_row = (frm.frm_w + frm.tile_w - 1) / frm.tile_w;
+    frm.tls_col = (frm.frm_h + frm.tile_h - 1) / frm.tile_h;
+    const int n_tiles = frm.tls_row * frm.tls_col;
+
+    /* camera model of tracer.cpp:1287-1322: ray(x, y) = dir + hor * x + ver * y from org */
+    double u[3], w2[3], ww[3], hl = 0.0, vl = 0.0;
+    for (int k = 0; k < 3; k++) { hl += (double)frm.hor[k] * frm.hor[k]; vl += (double)frm.ver[k] * frm.ver[k]; }
+    hl = __builtin_sqrt(hl); vl = __builtin_sqrt(vl);
+    bool cam_ok = hl > 0.0 && vl > 0.0;
+    double hv = 0.0;
+    if (cam_ok)
+    {
+        for (int k = 0; k < 3; k++) { u[k] = frm.hor[k] / hl; w2[k] = frm.ver[k] / vl; hv += u[k] * w2[k]; }
+        ww[0] = u[1] * w2[2] - u[2] * w2[1]; ww[1] = u[2] * w2[0] - u[0] * w2[2]; ww[2] = u[0] * w2[1] - u[1] * w2[0];
+        if (hv > 1e-6 || hv < -1e-6) cam_ok = false;           /* skewed image axes: fall back to full-screen rectangles */
+    }
+    double pov = 0.0, cx = 0.0, cy = 0.0;
+    if (cam_ok)
+    {
+        double du = 0.0, dv = 0.0;
+        for (int k = 0; k < 3; k++) { pov += frm.dir[k] * ww[k]; du += frm.dir[k] * u[k]; dv += frm.dir[k] * w2[k]; }
+        if (pov < 0.0) { pov = -pov; for (int k = 0; k < 3; k++) ww[k] = -ww[k]; }
+        if (!(pov > 1e-9)) cam_ok = false;
+        cx = -du / hl; cy = -dv / vl;
+    }
+
+    /* entries in camera-list order */
+    std::vector<BinEntry> ent;
+    std::vector<int> cell_of_entry, open_end_cell;              /* stack of the cells that end the open arrays */
+    std::vector<int> open_entry;
+    int guard = 0;
+    for (int c = frm.clist; c != QR_NULL; c = E[c].next)
+    {
+        if (++guard > (int)E.size()) return qr_fail(QR_ERR_ARG, "cyclic camera list");
+        const qr_elem &el = E[c];
+        const qr_surface &q = v.srf[el.simd];
+        BinEntry b; memset(&b, 0, sizeof(b));
+        b.simd = el.simd; b.data = el.data;
+        bool emit = true;
+        if ((el.kind & 3) == 1) emit = false;                   /* bounding-volume cell: tile lists carry none (engine.cpp:1711-1725) */
+        else if (q.srf_t[3] < 0)
+        {
+            b.marker = 1; b.end = -1;
+            if ((int)open_entry.size() >= QR_BIN_DEPTH) return qr_fail(QR_ERR_UNSUP, "transformed arrays nested deeper than the tile binning supports");
+        }
+        else
+        {
+            const BSphere &bs = bsph[el.simd];
+            b.x0 = 0; b.y0 = 0; b.x1 = frm.tls_row - 1; b.y1 = frm.tls_col - 1;
+            if (cam_ok && bs.r < 1e30f)
+            {
+                const double R = (double)bs.r * 1.001 + 1e-6;
+                double a = 0.0, bb = 0.0, z = 0.0;
+                for (int k = 0; k < 3; k++) { const double qk = (double)bs.c[k] - frm.org[k]; a += qk * u[k]; bb += qk * w2[k]; z += qk * ww[k]; }
+                double xl, xh, yl, yh;
+                const bool vx = screen_interval(a, z, R, cx, pov / hl, &xl, &xh);
+                const bool vy = screen_interval(bb, z, R, cy, pov / vl, &yl, &yh);
+                /* tighter: the projected corners of the surface's bounding box, when all of them lie in
+                 * front of the image plane (planes and clipped shapes fill their box far better than
+                 * their sphere) */
+                BBox bx;
+                (void)bound_sphere(v, el.simd, &bx);
+                if (bx.valid && vx && vy)
+                {
+                    double bxl = 1e300, bxh = -1e300, byl = 1e300, byh = -1e300; bool front = true;
+                    for (int c = 0; c < 8 && front; c++)
+                    {
+                        double pa = 0.0, pb = 0.0, pz = 0.0;
+                        for (int k = 0; k < 3; k++) { const double qk = bx.p[c][k] - frm.org[k]; pa += qk * u[k]; pb += qk * w2[k]; pz += qk * ww[k]; }
+                        if (!(pz > 1e-3 * pov)) { front = false; break; }
+                        const double sx = cx + (pa / pz) * (pov / hl), sy = cy + (pb / pz) * (pov / vl);
+                        if (sx < bxl) bxl = sx; if (sx > bxh) bxh = sx; if (sy < byl) byl = sy; if (sy > byh) byh = sy;
+                    }
+                    if (front)
+                    {
+                        /* a margin relative to the box size covers the 1e-3 inflation of the bounds */
+                        const double ex = 2e-3 * (bxh - bxl) + 1e-3, ey = 2e-3 * (byh - byl) + 1e-3;
+                        if (bxl - ex > xl) xl = bxl - ex; if (bxh + ex < xh) xh = bxh + ex;
+                        if (byl - ey > yl) yl = byl - ey; if (byh + ey < yh) yh = byh + ey;
+                    }
+                }
+                const double mg = 2.0;                              /* FSAA sample offsets (< 0.5 px) + fp32 ray rounding */
+                if (!vx || !vy || xh + mg < 0.0 || yh + mg < 0.0 || xl - mg > frm.frm_w || yl - mg > frm.frm_h) { b.x0 = 1; b.x1 = 0; }
+                else
+                {
+                    auto tl = [](double p, int ts, int nt, bool up) { double t = __builtin_floor(p / ts); if (t < 0) t = 0; if (t > nt - 1) t = nt - 1; (void)up; return (int32_t)t; };
+                    b.x0 = tl(xl - mg, frm.tile_w, frm.tls_row, false); b.x1 = tl(xh + mg, frm.tile_w, frm.tls_row, true);
+                    b.y0 = tl(yl - mg, frm.tile_h, frm.tls_col, false); b.y1 = tl(yh + mg, frm.tile_h, frm.tls_col, true);
+                }
+            }
+        }
+        if (emit)
+        {
+            if (b.marker) { open_entry.push_back((int)ent.size()); open_end_cell.push_back(el.data); }
+            ent.push_back(b);
+        }
+        /* close the arrays whose last cell this is (also when that cell itself was dropped) */
+        while (!open_entry.empty() && open_end_cell.back() == c)
+        {
+            ent[open_entry.back()].end = (int32_t)ent.size() - 1;
+            open_entry.pop_back(); open_end_cell.pop_back();
+        }
+    }
+    if (!open_entry.empty()) return qr_fail(QR_ERR_ARG, "array in the camera list does not end inside the list");
+
+    T.assign((size_t)n_tiles, QR_NULL);
+    if (ent.empty()) return QR_OK;
+
+    BinEntry *d_ent = nullptr; int32_t *d_cnt = nullptr, *d_off = nullptr, *d_heads = nullptr; qr_elem *d_cells = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_ent); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_heads); (void)hipFree(d_cells); };
+#define BIN_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return qr_fail(QR_ERR_DEVICE, std::string(#x ": ") + hipGetErrorString(e_)); } } while (0)
+    BIN_TRY(hipMalloc((void **)&d_ent, ent.size() * sizeof(BinEntry)));
+    BIN_TRY(hipMalloc((void **)&d_cnt, (size_t)n_tiles * 4));
+    BIN_TRY(hipMalloc((void **)&d_off, (size_t)n_tiles * 4));
+    BIN_TRY(hipMalloc((void **)&d_heads, (size_t)n_tiles * 4));
+    BIN_TRY(hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(BinEntry), hipMemcpyHostToDevice));
+    const dim3 blk(256), grd((unsigned)((n_tiles + 255) / 256));
+    hipLaunchKernelGGL((qr_bin_kernel<false>), grd, blk, 0, 0, d_ent, (int)ent.size(), frm.tls_row, n_tiles, d_cnt, (const int32_t *)nullptr, (qr_elem *)nullptr, (int32_t *)nullptr, 0);
+    BIN_TRY(hipGetLastError());
+    std::vector<int32_t> cnt((size_t)n_tiles), off((size_t)n_tiles);
+    BIN_TRY(hipMemcpy(cnt.data(), d_cnt, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (int i = 0; i < n_tiles; i++) { off[i] = (int32_t)total; total += (uint32_t)cnt[i]; }
+    if (total + E.size() > 0x7FFFFFF0ull) { cleanup(); return qr_fail(QR_ERR_NOMEM, "tile lists exceed the 31-bit cell index space"); }
+    const int cell_base = (int)E.size();
+    if (total > 0)
+    {
+        BIN_TRY(hipMalloc((void **)&d_cells, (size_t)total * sizeof(qr_elem)));
+        BIN_TRY(hipMemcpy(d_off, off.data(), (size_t)n_tiles * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL((qr_bin_kernel<true>), grd, blk, 0, 0, d_ent, (int)ent.size(), frm.tls_row, n_tiles, d_cnt, (const int32_t *)d_off, d_cells, d_heads, cell_base);
+        BIN_TRY(hipGetLastError());
+        E.resize((size_t)cell_base + total);
+        BIN_TRY(hipMemcpy(E.data() + cell_base, d_cells, (size_t)total * sizeof(qr_elem), hipMemcpyDeviceToHost));
+        BIN_TRY(hipMemcpy(T.data(), d_heads, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+#undef BIN_TRY
+    if (getenv("QR_VERBOSE"))
+        fprintf(stderr, "tile binning: %zu camera-list entries x %d tiles (%dx%d px) -> %llu cells\n", ent.size(), n_tiles, frm.tile_w, frm.tile_h, (unsigned long long)total);
+    return QR_OK;
+}
+
 extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene **out)
 {
+    return qr_scene_upload_ex(blob, size, device, 0u, out);
+}
+
+extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, uint32_t flags, qr_device_scene **out)
+{
     if (blob == nullptr || out == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    if (getenv("QR_REBIN") && atoi(getenv("QR_REBIN")) != 0) flags |= QR_UPLOAD_REBIN_TILES;
     qr_scene_view v;
     int rc = qr_scene_view_init(&v, blob, size);
     if (rc != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc) + ")");
@@ -254,6 +536,12 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                 if (const char *m = check_list(v.elm[e].data, 0)) return qr_fail(QR_ERR_ARG, m);
     }
 
+    /* working copies: the tile lists (and with them the cell array and the tile geometry of the
+     * frame record) are replaced when the binning pass runs */
+    std::vector<qr_elem> E(v.elm, v.elm + n_elm);
+    std::vector<int32_t> T(v.tiles, v.tiles + v.hdr->n_tiles);
+    qr_frame frm = *v.frame;
+
     /* ---- 1. build every device array on the host ---------------------------------------- */
 
     /* surfaces: repack qr_surface (256 B, snapshot layout) into DSurf (128 B, hot part first)
@@ -316,52 +604,62 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
         }
         fprintf(stderr, "bounding spheres: %d of %d real surfaces bounded\n", nfin, nreal);
     }
-    std::vector<qr_elem> cells(n_elm + 1);
-    memset(cells.data(), 0, cells.size() * sizeof(qr_elem));
-    memcpy(cells.data(), v.elm, (size_t)n_elm * sizeof(qr_elem));
+    if (flags & QR_UPLOAD_REBIN_TILES)
     {
-        std::vector<uint8_t> seen(n_elm + 1, 0);
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+            return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
+        if (device < 0 || device >= nd) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(device));
+        rc = rebin_tiles(v, bsph, frm, E, T);
+        if (rc != QR_OK) return rc;
+    }
+    std::vector<qr_elem> cells(E.size() + 1);
+    memset(cells.data(), 0, cells.size() * sizeof(qr_elem));
+    memcpy(cells.data(), E.data(), E.size() * sizeof(qr_elem));
+    {
+        std::vector<uint8_t> seen(E.size() + 1, 0);
         const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
         const int cull_mode = getenv("QR_NOCULL") ? 0 : (cm ? atoi(cm) : 3);
         auto mark_list = [&](int head) {
-            for (int e = head; e != QR_NULL && !seen[e]; e = v.elm[e].next)
+            for (int e = head; e != QR_NULL && !seen[e]; e = E[e].next)
             {
                 seen[e] = 1;
-                const int si = v.elm[e].simd;
+                const int si = E[e].simd;
                 const qr_surface &q = v.srf[si];
                 const bool real = q.srf_t[3] >= 0 && q.srf_t[3] < QR_TAG_SURFACE_MAX;
                 /* the solver already rejects a ray that misses a closed quadric as cheaply as the sphere test
                  * does; the test pays for planes and open quadrics, whose hits die only in the clippers */
                 const bool open_shape = q.srf_t[0] == 1 || !(q.sci[0] > 0.0f && q.sci[1] > 0.0f && q.sci[2] > 0.0f);
                 const bool want = cull_mode >= 3 || (cull_mode == 2 && open_shape) || (cull_mode == 1 && q.srf_t[0] == 1);
-                if (real && (v.elm[e].kind & 3) == 0 && bsph[si].r < 1e30f && want) cells[e].kind |= 4;
+                if (real && (E[e].kind & 3) == 0 && bsph[si].r < 1e30f && want) cells[e].kind |= 4;
             }
         };
-        for (uint32_t i = 0; i < v.hdr->n_tiles; i++) mark_list(v.tiles[i]);
-        mark_list(fr.clist);
+        for (uint32_t i = 0; i < (uint32_t)T.size(); i++) mark_list(T[i]);
+        mark_list(frm.clist);
         for (int i = 0; i < n_srf; i++)
         {
             const qr_surface &q = v.srf[i];
             if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
             mark_list(q.lst[1]); mark_list(q.lst[3]);
             for (int side = 0; side < 2; side++)
-                for (int e = q.lst[side * 2]; e != QR_NULL; e = v.elm[e].next) mark_list(v.elm[e].data);
+                for (int e = q.lst[side * 2]; e != QR_NULL; e = E[e].next) mark_list(E[e].data);
         }
     }
     for (int i = 0; i < n_srf; i++) for (int k = 0; k < 4; k++) dshade[i].lst[k] = v.srf[i].lst[k];
 
     /* wave schedule: one entry per wave footprint (8x8 / 8x4 / 4x4 pixels) */
-    const int fw = fr.fsaa == 2 ? 4 : 8, fh = fr.fsaa == 0 ? 8 : 4;
-    const int nbx = (fr.frm_w + fw - 1) / fw, nby = (fr.frm_h + fh - 1) / fh;
+    const int fw = frm.fsaa == 2 ? 4 : 8, fh = frm.fsaa == 0 ? 8 : 4;
+    const int nbx = (frm.frm_w + fw - 1) / fw, nby = (frm.frm_h + fh - 1) / fh;
     if (nbx > 0x3FFF || nby > 0x3FFF) return qr_fail(QR_ERR_ARG, "frame too large");
     std::vector<uint32_t> order;
     {
         /* heavy = the footprint's tile list holds a reflective or non-opaque surface */
-        std::vector<uint8_t> tile_heavy((size_t)fr.tls_row * fr.tls_col, 0);
+        std::vector<uint8_t> tile_heavy((size_t)frm.tls_row * frm.tls_col, 0);
         for (size_t t = 0; t < tile_heavy.size(); t++)
-            for (int e = v.tiles[t]; e != QR_NULL; e = v.elm[e].next)
+            for (int e = T[t]; e != QR_NULL; e = E[e].next)
             {
-                const qr_surface &q = v.srf[v.elm[e].simd];
+                const qr_surface &q = v.srf[E[e].simd];
                 if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
                 for (int k = 0; k < 2; k++)
                 {
@@ -379,8 +677,8 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
                     {
                         const int bx = tx * gx + i, by = ty * gy + j;
                         if (bx >= nbx || by >= nby) continue;
-                        const int tlx = (bx * fw) / fr.tile_w, tly = (by * fh) / fr.tile_h;
-                        const int hv = (tlx < fr.tls_row && tly < fr.tls_col) ? tile_heavy[(size_t)tly * fr.tls_row + tlx] : 0;
+                        const int tlx = (bx * fw) / frm.tile_w, tly = (by * fh) / frm.tile_h;
+                        const int hv = (tlx < frm.tls_row && tly < frm.tls_col) ? tile_heavy[(size_t)tly * frm.tls_row + tlx] : 0;
                         const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14);
                         (hv ? heavy : light).push_back(ent);
                     }
@@ -396,7 +694,7 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     size_t o_lgt = pad16(o_mat + (size_t)(n_mat + 1) * sizeof(qr_material));
     size_t o_elm = pad16(o_lgt + (size_t)(n_lgt + 1) * sizeof(qr_light));
     size_t o_til = pad16(o_elm + cells.size() * sizeof(DCell));
-    size_t o_tex = pad16(o_til + (size_t)(v.hdr->n_tiles + 1) * 4);
+    size_t o_tex = pad16(o_til + (size_t)((uint32_t)T.size() + 1) * 4);
     size_t o_ord = pad16(o_tex + (size_t)(n_tex + 1) * 4);
     size_t o_frm = pad16(o_ord + order.size() * 4 + 16);
     size_t o_bs = pad16(o_frm + sizeof(qr_frame));
@@ -422,10 +720,10 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
         }
         memcpy(host.data() + o_elm, dc.data(), dc.size() * sizeof(DCell));
     }
-    memcpy(host.data() + o_til, v.tiles, (size_t)v.hdr->n_tiles * 4);
+    memcpy(host.data() + o_til, T.data(), T.size() * 4);
     memcpy(host.data() + o_tex, v.texels, (size_t)n_tex * 4);
     memcpy(host.data() + o_ord, order.data(), order.size() * 4);
-    memcpy(host.data() + o_frm, &fr, sizeof(qr_frame));
+    memcpy(host.data() + o_frm, &frm, sizeof(qr_frame));
     memcpy(host.data() + o_bs, bsph.data(), bsph.size() * sizeof(BSphere));
 
     int ndev = 0;
@@ -465,12 +763,13 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
     s->sc.n_blocks = (int32_t)order.size();
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
-    s->fr = fr;
-    s->sc.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
-    s->sc.row_begin = 0; s->sc.row_end = fr.frm_h;
-    s->sc.index = fr.index; s->sc.thnum = fr.thnum > 0 ? fr.thnum : 1;
+    s->fr = frm;
+    s->n_cells = E.size();
+    s->sc.depth = frm.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : frm.depth;
+    s->sc.row_begin = 0; s->sc.row_end = frm.frm_h;
+    s->sc.index = frm.index; s->sc.thnum = frm.thnum > 0 ? frm.thnum : 1;
     s->sc.group_first = 0; s->sc.group_stride = 1;
-    s->sc.n_groups = (fr.frm_h + 7) / 8;
+    s->sc.n_groups = (frm.frm_h + 7) / 8;
     s->sc.dbg = getenv("QR_DBG") ? atoi(getenv("QR_DBG")) : 0;
     *out = s;
     return QR_OK;
@@ -495,7 +794,7 @@ extern "C" int qr_scene_get_info(const qr_device_scene *s, qr_scene_info *info)
     info->frm_w = s->fr.frm_w; info->frm_h = s->fr.frm_h;
     info->fsaa = s->fr.fsaa; info->depth = s->sc.depth;
     info->n_srf = (int32_t)s->hdr.n_srf; info->n_mat = (int32_t)s->hdr.n_mat; info->n_lgt = (int32_t)s->hdr.n_lgt;
-    info->n_elm = (int32_t)s->hdr.n_elm; info->n_tiles = (int32_t)s->hdr.n_tiles; info->n_texels = (int32_t)s->hdr.n_texels;
+    info->n_elm = (int32_t)s->n_cells; info->n_tiles = s->fr.tls_row * s->fr.tls_col; info->n_texels = (int32_t)s->hdr.n_texels;
     info->tile_w = s->fr.tile_w; info->tile_h = s->fr.tile_h;
     info->device_bytes = s->blob_bytes;
     return QR_OK;

@@ -113,3 +113,33 @@ def test_gpu_drop_in_through_reference_engine():
         out = subprocess.run([exe] + args + ["--gpu"], cwd=tmp, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + BIG_CASES)
+def test_gpu_tile_binning_keeps_frames(qr, name):
+    """QR_UPLOAD_REBIN_TILES: tile lists rebuilt on the GPU from the camera list (replaces the engine's
+    host tiling, engine.cpp:1956-2128) give the reference's pixels, hit ids and ray counts."""
+    import torch
+    blob = load_blob(name)
+    scn = qr.Scene(blob, rebin_tiles=True)
+    frame = scn.new_frame(); ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids); torch.cuda.synchronize()
+    out = frame.cpu().numpy().view(np.uint32)
+    if name in BIG_CASES:
+        assert _hash(out) == int(MANIFEST[name]["hash"], 16)
+    else:
+        assert (out == (load_frame(name) & 0xFFFFFF)).all()
+    base = qr.Scene(blob)
+    f0 = base.new_frame(); i0 = torch.full_like(f0, -2)
+    base.render(f0, ids=i0); torch.cuda.synchronize()
+    assert bool((f0 == frame).all()) and bool((i0 == ids).all())
+    _, c0 = base.render_count(); _, c1 = scn.render_count()
+    assert c0.as_dict() == c1.as_dict()
+
+
+def _hash(frame):
+    """FNV-1a-64 over pixel & 0xFFFFFF, row-major (tests/golden/manifest.json 'hash'): the oracle's C helper."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import qr_oracle
+    return qr_oracle.frame_hash(frame)
