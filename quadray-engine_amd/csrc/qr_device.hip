@@ -90,6 +90,31 @@ static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
             for (int a = 0; a < 3; a++)
             {
                 const double sa = q.sci[a];
+                if (sa == 0.0 && q.scj[a] != 0.0f)
+                {
+                    /* linear axis (paraboloids): 2 scj_a x_a = sum_{b != a} (sci_b x_b^2 - 2 scj_b x_b) - sci_w */
+                    double L = -(double)q.sci[3], U = -(double)q.sci[3];
+                    for (int b = 0; b < 3; b++)
+                    {
+                        if (b == a) continue;
+                        const double sb = q.sci[b], jb = q.scj[b];
+                        const double m2 = (lo[b] * lo[b] > hi[b] * hi[b]) ? lo[b] * lo[b] : hi[b] * hi[b];   /* max x^2 */
+                        if (sb > 0.0) { U += (m2 < INF / 4) ? sb * m2 : INF; }
+                        else if (sb < 0.0) { L += (m2 < INF / 4) ? sb * m2 : -INF; }
+                        if (jb != 0.0)
+                        {
+                            const double e0 = -2.0 * jb * lo[b], e1 = -2.0 * jb * hi[b];
+                            const double mn = e0 < e1 ? e0 : e1, mx = e0 > e1 ? e0 : e1;
+                            L += (mn > -INF / 4) ? mn : -INF; U += (mx < INF / 4) ? mx : INF;
+                        }
+                    }
+                    const double d2 = 2.0 * (double)q.scj[a];
+                    double l = (d2 > 0.0 ? L : U) / d2, h = (d2 > 0.0 ? U : L) / d2;
+                    if (l > -INF / 8) { l -= 1e-4 + 5e-4 * (l < 0 ? -l : l); if (lo[a] < l) lo[a] = l; }
+                    if (h < INF / 8) { h += 1e-4 + 5e-4 * (h < 0 ? -h : h); if (hi[a] > h) hi[a] = h; }
+                    if (lo[a] > hi[a]) lo[a] = hi[a] = 0.5 * (lo[a] + hi[a]);
+                    continue;
+                }
                 if (!(sa > 0.0) || q.scj[a] != 0.0f) continue;
                 double rhs = q.sci[3];
                 bool ok = true;
@@ -481,13 +506,24 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
         if (((uint64_t)m.ymask << (m.yshft & 31)) + m.xmask >= n) return qr_fail(QR_ERR_ARG, "texture addressing exceeds texture");
     }
     /* classify lists: walk every list once with a step bound (cycle check) */
+    std::vector<uint8_t> checked((size_t)n_elm + 1, 0);     /* bit k: head already validated as a list of kind k */
+    /* are the bounding-volume arrays of every surface list properly nested (each array ends inside the
+     * array that contains its head)?  The engine builds them that way; the kernel's packet jump over an
+     * array relies on it, so it is checked here and the jump narrowed when it does not hold. */
+    bool nested = true;
+    std::vector<int> pos_stamp((size_t)n_elm + 1, -1), pos_idx((size_t)n_elm + 1, 0);
+    int stamp = 0;
     auto check_list = [&](int head, int kind) -> const char * {
         /* kind 0 surfaces, 1 clippers, 2 lights */
+        if (head == QR_NULL) return nullptr;
+        if (checked[head] & (1u << kind)) return nullptr;     /* shared lists (one global list per scene) are walked once */
+        checked[head] |= (uint8_t)(1u << kind);
         int cnt = 0;
         for (int e = head; e != QR_NULL; e = v.elm[e].next)
         {
             if (++cnt > n_elm) return "cyclic list";
             const qr_elem &el = v.elm[e];
+            if (kind == 0) { pos_stamp[e] = stamp; pos_idx[e] = cnt; }
             if (kind == 2)
             {
                 if (el.simd < 0 || el.simd >= n_lgt) return "light index out of range";
@@ -506,6 +542,24 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
                     if (v.srf[el.simd].srf_t[3] < 0 && !ok_elm(el.data)) return "clip trnode last out of range";
                 }
             }
+        }
+        if (kind == 0)
+        {
+            std::vector<int> open_end;          /* list positions at which the open arrays end */
+            int p = 0;
+            for (int e = head; e != QR_NULL; e = v.elm[e].next)
+            {
+                p++;
+                while (!open_end.empty() && open_end.back() < p) open_end.pop_back();
+                const qr_elem &el = v.elm[e];
+                if ((el.kind & 3) == 1)
+                {
+                    if (el.data == QR_NULL || pos_stamp[el.data] != stamp || pos_idx[el.data] < p) { nested = false; break; }
+                    if (!open_end.empty() && pos_idx[el.data] > open_end.back()) { nested = false; break; }
+                    open_end.push_back(pos_idx[el.data]);
+                }
+            }
+            stamp++;
         }
         return nullptr;
     };
@@ -761,6 +815,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->sc.bsph = (const void *)(d + o_bs);
     s->sc.order = (const uint32_t *)(d + o_ord);
     s->sc.n_blocks = (int32_t)order.size();
+    s->sc.nested = nested ? 1 : 0;
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
     s->fr = frm;

@@ -124,6 +124,7 @@ struct DevScene
     const void        *__restrict__ bsph;   /* float4 per surface: world-space bounding sphere (cx,cy,cz,r) */
     const uint32_t    *__restrict__ order;  /* wave schedule: bx | by << 14, heavy footprints first */
     int32_t n_blocks;
+    int32_t nested;             /* every surface list's arrays are properly nested (checked at upload) */
     unsigned long long *stats;    /* QR_STATS builds only: walk statistics */
     int32_t dbg;                  /* timing experiments only (QR_DBG): 1 no shadow walks, 2 no lights */
 };
@@ -810,9 +811,14 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
     /*
      * The reference jumps a whole packet to the end of an array whose bounding volume no lane hits
      * (tracer.cpp:4040-4054); here rays skip individually, so take the jump when this array head
-     * left every live ray of the group waiting for its last element.
+     * left no live ray of the group walking.  Rays that were skipping already wait for the end of an
+     * enclosing array, which lies at or behind this array's end when arrays are properly nested
+     * (sc.nested, verified at upload); otherwise jump only if all rays wait for this array's end.
      */
-    if ((el.kind & 3) == 1 && !__any(live && w.resume != el.data)) return el.data;
+    if ((el.kind & 3) == 1)
+    {
+        if (sc.nested ? !__any(live && w.resume == QR_NULL) : !__any(live && w.resume != el.data)) return el.data;
+    }
     return QR_NULL;
 }
 
