@@ -118,7 +118,7 @@ class _Builder:
 
 
 def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, box=100.0, gamma=False, fsaa=0,
-               hierarchy=True):
+               hierarchy=True, leaf=16):
     """Return the snapshot bytes of the synthetic scene.  hierarchy=False writes one flat list without
     bounding-volume elements (same image, used by the tests to check that the volumes are conservative)."""
     rng = _Rng(seed)
@@ -219,7 +219,6 @@ def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, bo
         r_cells, r_sph = build(order[len(order) // 2:])
         return array(l_cells + r_cells, [l_sph, r_sph])
 
-    leaf = 4
     top_cells = [b.cell(ground)]
     if hierarchy and obj:
         top_cells += build(list(range(len(obj))))[0]

@@ -10,7 +10,7 @@ spec = importlib.util.spec_from_file_location("qr_synth", os.path.join(ROOT, "qu
 synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
 n, w, h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 depth = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-t = time.time(); blob = synth.make_scene(n_objects=n, width=w, height=h, depth=depth); t_gen = time.time() - t
+t = time.time(); blob = synth.make_scene(n_objects=n, width=w, height=h, depth=depth, leaf=int(os.environ.get('QR_SYNTH_LEAF', '4'))); t_gen = time.time() - t
 t = time.time(); scn = qr.Scene(blob, rebin_tiles=True); t_up = time.time() - t
 f = scn.new_frame()
 t = time.time(); _, c = scn.render_count(f); t_cnt = time.time() - t
