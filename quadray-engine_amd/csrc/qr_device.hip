@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 #include <utility>
 #include <string>
 
@@ -992,28 +993,59 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     return QR_OK;
 }
 
+/* per-thread device frame + pinned staging buffer, kept between calls: the drop-in path renders a frame
+ * per call, and hipMalloc/hipFree plus a pageable 8 MB copy cost more than the kernel itself */
+struct HostPathCache
+{
+    int device = -1;
+    void *d_frame = nullptr; size_t d_cap = 0;
+    uint32_t *h_frame = nullptr; size_t h_cap = 0;
+    ~HostPathCache()
+    {
+        /* the HIP runtime may already be shut down when thread-locals are destroyed at exit: leak */
+    }
+};
+static thread_local HostPathCache g_hpc;
+
 extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_pixels)
 {
     if (s == nullptr || frame_host == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     const int w = s->fr.frm_w, h = s->fr.frm_h;
+    const size_t bytes = (size_t)w * h * 4;
     HIP_TRY(hipSetDevice(s->device));
-    void *d_frame = nullptr;
-    HIP_TRY(hipMalloc(&d_frame, (size_t)w * h * 4));
-    int rc = QR_OK;
-    hipError_t e = launch<false>(s, d_frame, nullptr, nullptr);
-    std::vector<uint32_t> tmp((size_t)w * h);
-    if (e == hipSuccess) e = hipMemcpy(tmp.data(), d_frame, (size_t)w * h * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d_frame);
+    HostPathCache &c = g_hpc;
+    if (c.device != s->device || c.d_cap < bytes)
+    {
+        if (c.d_frame) { (void)hipSetDevice(c.device); (void)hipFree(c.d_frame); (void)hipSetDevice(s->device); }
+        c.d_frame = nullptr; c.d_cap = 0; c.device = s->device;
+        HIP_TRY(hipMalloc(&c.d_frame, bytes));
+        c.d_cap = bytes;
+    }
+    if (c.h_cap < bytes)
+    {
+        if (c.h_frame) (void)hipHostFree(c.h_frame);
+        c.h_frame = nullptr; c.h_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&c.h_frame, bytes, hipHostMallocDefault));
+        c.h_cap = bytes;
+    }
+    hipError_t e = launch<false>(s, c.d_frame, nullptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(c.h_frame, c.d_frame, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     /* copy only the rows this call owns, honouring a negative stride (bottom-up
      * frames, engine.cpp:2814-2850) */
+    const bool whole = s->sc.row_begin == 0 && s->sc.row_end == h && s->sc.group_first == 0 && s->sc.group_stride == 1 && s->sc.thnum <= 1;
+    if (whole && row_pixels == w)
+    {
+        memcpy(frame_host, c.h_frame, bytes);
+        return QR_OK;
+    }
     for (int y = s->sc.row_begin; y < s->sc.row_end; y++)
     {
         if ((y / 8 - s->sc.group_first) % s->sc.group_stride != 0 || y / 8 < s->sc.group_first) continue;
         if (s->sc.thnum > 1 && (y % s->sc.thnum) != s->sc.index) continue;
-        memcpy(frame_host + (ptrdiff_t)y * row_pixels, tmp.data() + (size_t)y * w, (size_t)w * 4);
+        memcpy(frame_host + (ptrdiff_t)y * row_pixels, c.h_frame + (size_t)y * w, (size_t)w * 4);
     }
-    return rc;
+    return QR_OK;
 }
 
 /*
@@ -1022,12 +1054,20 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
  * and animates objects every frame (engine.cpp:2976-3332); all of that is a few
  * hundred KB.
  */
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
 {
+    const bool verbose = getenv("QR_VERBOSE") != nullptr;
+    const double t0 = now_ms();
     std::vector<uint8_t> blob;
     std::string err;
     int rc = qr_flatten_impl(s_inf, abi, blob, err);
     if (rc != QR_OK) return qr_fail(rc, err);
+    const double t1 = now_ms();
 
     /* frame pointer and stride: inf_FRAME / inf_FRM_ROW, tracer.h:186-190 */
     const uint8_t *inf = (const uint8_t *)s_inf;
@@ -1043,7 +1083,12 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     qr_device_scene *scn = nullptr;
     rc = qr_scene_upload(blob.data(), blob.size(), dev, &scn);
     if (rc != QR_OK) return rc;
+    const double t2 = now_ms();
     rc = qr_render_host(scn, (uint32_t *)(uintptr_t)p_frame, (int)row);
+    const double t3 = now_ms();
     qr_scene_destroy(scn);
+    if (verbose)
+        fprintf(stderr, "qr_render0: flatten %.3f ms (%zu bytes), upload %.3f ms, render+copy %.3f ms, destroy %.3f ms\n",
+                t1 - t0, blob.size(), t2 - t1, t3 - t2, now_ms() - t3);
     return rc;
 }

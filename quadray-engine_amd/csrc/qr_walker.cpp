@@ -16,7 +16,6 @@
 
 #include <cstring>
 #include <cstdlib>
-#include <unordered_map>
 #include <vector>
 #include <deque>
 
@@ -66,6 +65,45 @@ inline ElemRaw rd_elem(const Abi &a, uint64_t p)
 
 enum ListKind { LIST_SURFACES, LIST_CLIPPERS, LIST_LIGHTS };
 
+/*
+ * pointer -> dense index map: open addressing, linear probing, grows by doubling.  The element map
+ * sees every list cell of the frame (tens of thousands per call, every frame), where node-based
+ * std::unordered_map spent most of the flatten time in its allocator.
+ */
+class PtrMap
+{
+    std::vector<uint64_t> keys;         /* 0 = empty (NULL is never a key) */
+    std::vector<int32_t>  vals;
+    size_t used = 0;
+    static size_t slot(uint64_t k, size_t mask) { return (size_t)((k >> 4) * 0x9E3779B97F4A7C15ull >> 17) & mask; }
+    void grow()
+    {
+        const size_t n = keys.empty() ? 1024 : keys.size() * 2;
+        std::vector<uint64_t> k(n, 0); std::vector<int32_t> v(n, 0);
+        for (size_t i = 0; i < keys.size(); i++)
+            if (keys[i]) { size_t j = slot(keys[i], n - 1); while (k[j]) j = (j + 1) & (n - 1); k[j] = keys[i]; v[j] = vals[i]; }
+        keys.swap(k); vals.swap(v);
+    }
+public:
+    const int32_t *find(uint64_t key) const
+    {
+        if (keys.empty()) return nullptr;
+        const size_t mask = keys.size() - 1;
+        for (size_t j = slot(key, mask); keys[j]; j = (j + 1) & mask) if (keys[j] == key) return &vals[j];
+        return nullptr;
+    }
+    void put(uint64_t key, int32_t val)
+    {
+        if ((used + 1) * 2 > keys.size()) grow();
+        const size_t mask = keys.size() - 1;
+        size_t j = slot(key, mask);
+        while (keys[j] && keys[j] != key) j = (j + 1) & mask;
+        if (!keys[j]) used++;
+        keys[j] = key; vals[j] = val;
+    }
+    int32_t at(uint64_t key) const { const int32_t *p = find(key); return p ? *p : QR_NULL; }
+};
+
 struct Walker
 {
     Abi a;
@@ -74,7 +112,7 @@ struct Walker
     std::vector<qr_light>    lgt;
     std::vector<qr_elem>     elm;
     std::vector<uint32_t>    texels;
-    std::unordered_map<uint64_t, int32_t> srf_ix, mat_ix, lgt_ix, elm_ix, tex_ix;
+    PtrMap srf_ix, mat_ix, lgt_ix, elm_ix, tex_ix;
     std::deque<uint64_t> srf_todo;
     std::string err;
 
@@ -87,10 +125,9 @@ struct Walker
     int32_t get_srf(uint64_t p)
     {
         if (p == 0) return QR_NULL;
-        auto it = srf_ix.find(p);
-        if (it != srf_ix.end()) return it->second;
+        if (const int32_t *it = srf_ix.find(p)) return *it;
         int32_t ix = (int32_t)srf.size();
-        srf_ix[p] = ix;
+        srf_ix.put(p, ix);
         qr_surface s; memset(&s, 0, sizeof(s));
         srf.push_back(s);
         srf_todo.push_back(p);
@@ -100,8 +137,7 @@ struct Walker
     int32_t get_lgt(uint64_t p)
     {
         if (p == 0) return QR_NULL;
-        auto it = lgt_ix.find(p);
-        if (it != lgt_ix.end()) return it->second;
+        if (const int32_t *it = lgt_ix.find(p)) return *it;
         const uint8_t *l = (const uint8_t *)(uintptr_t)p;
         const size_t q = a.Q * 0x10;
         qr_light o; memset(&o, 0, sizeof(o));
@@ -119,28 +155,26 @@ struct Walker
         o.a_rng  = rd_f32(l, q * 0xB);
         int32_t ix = (int32_t)lgt.size();
         lgt.push_back(o);
-        lgt_ix[p] = ix;
+        lgt_ix.put(p, ix);
         return ix;
     }
 
     int32_t get_tex(uint64_t p, uint32_t xdim, uint32_t ydim)
     {
         if (p == 0) return QR_NULL;
-        auto it = tex_ix.find(p);
-        if (it != tex_ix.end()) return it->second;
+        if (const int32_t *it = tex_ix.find(p)) return *it;
         int32_t off = (int32_t)texels.size();
         const uint32_t *t = (const uint32_t *)(uintptr_t)p;
         size_t n = (size_t)xdim * ydim;
         texels.insert(texels.end(), t, t + n);
-        tex_ix[p] = off;
+        tex_ix.put(p, off);
         return off;
     }
 
     int32_t get_mat(uint64_t p)
     {
         if (p == 0) return QR_NULL;
-        auto it = mat_ix.find(p);
-        if (it != mat_ix.end()) return it->second;
+        if (const int32_t *it = mat_ix.find(p)) return *it;
         const uint8_t *m = (const uint8_t *)(uintptr_t)p;
         const size_t q = a.Q * 0x10;
         qr_material o; memset(&o, 0, sizeof(o));
@@ -174,7 +208,7 @@ struct Walker
         o.tex = get_tex(tex, o.xmask + 1, o.ymask + 1);
         int32_t ix = (int32_t)mat.size();
         mat.push_back(o);
-        mat_ix[p] = ix;
+        mat_ix.put(p, ix);
         return ix;
     }
 
@@ -188,15 +222,14 @@ struct Walker
     int32_t walk_list(uint64_t head, ListKind kind)
     {
         if (head == 0) return QR_NULL;
-        auto known = elm_ix.find(head);
-        if (known != elm_ix.end()) return known->second;
+        if (const int32_t *known = elm_ix.find(head)) return *known;
 
         std::vector<uint64_t> fresh;
         for (uint64_t p = head; p != 0; )
         {
-            if (elm_ix.count(p)) break;
+            if (elm_ix.find(p)) break;
             int32_t ix = (int32_t)elm.size();
-            elm_ix[p] = ix;
+            elm_ix.put(p, ix);
             qr_elem e; e.simd = QR_NULL; e.data = QR_NULL; e.next = QR_NULL; e.kind = 0;
             elm.push_back(e);
             fresh.push_back(p);
@@ -222,9 +255,9 @@ struct Walker
                 uint64_t last = (uint64_t)r.data & ~(uint64_t)3;
                 if (last != 0)
                 {
-                    auto it = elm_ix.find(last);
-                    if (it == elm_ix.end()) { err = "array element's last element is outside its list"; return QR_NULL; }
-                    e.data = it->second;
+                    const int32_t *it = elm_ix.find(last);
+                    if (!it) { err = "array element's last element is outside its list"; return QR_NULL; }
+                    e.data = *it;
                 }
                 break;
             }
@@ -240,9 +273,9 @@ struct Walker
                     e.simd = get_srf(r.simd);
                     if (srf_tag(r.simd) < 0)
                     {
-                        auto it = elm_ix.find((uint64_t)r.data);
-                        if (it == elm_ix.end()) { err = "clip trnode's last element is outside its list"; return QR_NULL; }
-                        e.data = it->second;
+                        const int32_t *it = elm_ix.find((uint64_t)r.data);
+                        if (!it) { err = "clip trnode's last element is outside its list"; return QR_NULL; }
+                        e.data = *it;
                         e.kind = 2;                     /* trnode marker in clip lists */
                     }
                     else
