@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <chrono>
 #include <utility>
 #include <string>
@@ -737,9 +738,25 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
                         const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14);
                         (hv ? heavy : light).push_back(ent);
                     }
-        order = heavy;
-        order.insert(order.end(), light.begin(), light.end());
+        heavy.insert(heavy.end(), light.begin(), light.end());
+        /* second word: the footprint's tile-list head when all its pixels lie in one tile (always, for the
+         * engine's 32x8 tiles), so that the wave needs no per-lane tile lookup */
+        order.reserve(heavy.size() * 2);
+        for (uint32_t ent : heavy)
+        {
+            const int bx = (int)(ent & 0x3FFFu), by = (int)((ent >> 14) & 0x3FFFu);
+            const int x0 = bx * fw, y0 = by * fh;
+            const int x1 = std::min(x0 + fw - 1, frm.frm_w - 1), y1 = std::min(y0 + fh - 1, frm.frm_h - 1);
+            int32_t head = QR_PER_LANE_TILE;
+            if (x0 / frm.tile_w == x1 / frm.tile_w && y0 / frm.tile_h == y1 / frm.tile_h)
+            {
+                const int tlx = x0 / frm.tile_w, tly = y0 / frm.tile_h;
+                if (tlx < frm.tls_row && tly < frm.tls_col) head = T[(size_t)tly * frm.tls_row + tlx];
+            }
+            order.push_back(ent); order.push_back((uint32_t)head);
+        }
     }
+    const size_t n_sched = order.size() / 2;
 
     /* ---- 2. one device allocation; arrays padded by one zero record so that masked-off
      *         lanes may read index 0 of an empty array ------------------------------------ */
@@ -796,7 +813,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
 #ifdef QR_WAVETIME
-    e = hipMalloc((void **)&s->d_counters, (32 + 4 * order.size()) * sizeof(unsigned long long));
+    e = hipMalloc((void **)&s->d_counters, (32 + QR_WT_SLOTS * n_sched) * sizeof(unsigned long long));
 #else
     e = hipMalloc((void **)&s->d_counters, 32 * sizeof(unsigned long long));
 #endif
@@ -815,7 +832,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->sc.texels = (const uint32_t *)(d + o_tex);
     s->sc.bsph = (const void *)(d + o_bs);
     s->sc.order = (const uint32_t *)(d + o_ord);
-    s->sc.n_blocks = (int32_t)order.size();
+    s->sc.n_blocks = (int32_t)n_sched;
     s->sc.nested = nested ? 1 : 0;
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
@@ -970,6 +987,9 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     double sum = 0.0; float mn = 1e30f;
     for (int i = 0; i < iters; i++)
     {
+#ifdef QR_WAVETIME
+        HIP_TRY(hipMemsetAsync(s->d_counters + 32, 0, (size_t)s->sc.n_blocks * QR_WT_SLOTS * sizeof(unsigned long long), st));
+#endif
         HIP_TRY(hipEventRecord(s->ev0, st));
         HIP_TRY(launch<false>(s, frame_dev, nullptr, st));
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -984,7 +1004,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     if (const char *path = getenv("QR_WAVETIME_OUT"))
     {
         /* per wave of the last launch: {start, first traverse done, end} in 100 MHz ticks, {hw_id | xcc << 32 | walks << 40} */
-        std::vector<unsigned long long> w((size_t)s->sc.n_blocks * 4);
+        std::vector<unsigned long long> w((size_t)s->sc.n_blocks * QR_WT_SLOTS);
         HIP_TRY(hipMemcpy(w.data(), s->d_counters + 32, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         FILE *f = fopen(path, "wb");
         if (f) { fwrite(w.data(), sizeof(unsigned long long), w.size(), f); fclose(f); }

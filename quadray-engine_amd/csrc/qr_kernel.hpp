@@ -51,6 +51,8 @@
 #ifndef QR_MAX_DEPTH
 #define QR_MAX_DEPTH 10           /* RT_STACK_DEPTH, tracer.h:46 */
 #endif
+#define QR_PER_LANE_TILE (-2) /* schedule entry: the footprint straddles tiles, look the list up per pixel */
+#define QR_WT_SLOTS 12       /* QR_WAVETIME builds: u64 slots per wave */
 #ifndef QR_PIPE
 #define QR_PIPE 0                 /* list-walk prefetch depth: 0 none, 1 next cell, 2 next cell + next record */
 #endif
@@ -122,7 +124,7 @@ struct DevScene
     int32_t index, thnum;         /* reference row interleave                */
     int32_t group_first, group_stride, n_groups; /* 8-row groups: first + k*stride */
     const void        *__restrict__ bsph;   /* float4 per surface: world-space bounding sphere (cx,cy,cz,r) */
-    const uint32_t    *__restrict__ order;  /* wave schedule: bx | by << 14, heavy footprints first */
+    const uint32_t    *__restrict__ order;  /* wave schedule, 8 B per wave: {bx | by << 14, tile-list head}, heavy footprints first */
     int32_t n_blocks;
     int32_t nested;             /* every surface list's arrays are properly nested (checked at upload) */
     unsigned long long *stats;    /* QR_STATS builds only: walk statistics */
@@ -850,9 +852,15 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
 #else
 #define QR_T(x)
 #endif
+#ifdef QR_WAVETIME
+    unsigned long long wt_cells = 0;
+#endif
     while (e != QR_NULL)
     {
         e = __builtin_amdgcn_readfirstlane(e);
+#ifdef QR_WAVETIME
+        wt_cells++;
+#endif
         QR_T(t0);
         const CellS cs = ld_cell(E + e);
         const qr_elem el = cs.el;
@@ -914,6 +922,14 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         if (SHADOW && !__any(live)) break;
         e = jump != QR_NULL ? jump : el.next;
     }
+#ifdef QR_WAVETIME
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        const size_t gw_ = (size_t)blockIdx.x * (QR_BLOCK / 64) + (threadIdx.x >> 6);
+        unsigned long long *o = sc.stats + 28 + gw_ * QR_WT_SLOTS;
+        o[SHADOW ? 4 : 5] += wt_cells; o[SHADOW ? 6 : 7] += 1;
+    }
+#endif
 #ifdef QR_STATS2
     if (SHADOW && __ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
     {
@@ -1147,7 +1163,14 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
 #ifdef QR_X_NOSHADOW
             occ = false; sh.si = 0;
 #else
+#ifdef QR_WAVETIME
+            const unsigned long long wt_a = __builtin_amdgcn_s_memrealtime();
+#endif
             traverse<true>(sc, lm, sr, sh, occ);
+#ifdef QR_WAVETIME
+            if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+                sc.stats[28 + ((size_t)blockIdx.x * (QR_BLOCK / 64) + (threadIdx.x >> 6)) * QR_WT_SLOTS + 10] += __builtin_amdgcn_s_memrealtime() - wt_a;
+#endif
 #endif
         }
         if (lm && !occ)
@@ -1440,16 +1463,21 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
      * long waves overlap the bulk instead of forming a tail); consecutive entries are
      * neighbouring footprints, so the waves of a workgroup still share tile lists. */
     const int fw = fsaa == 2 ? 4 : 8, fh = fsaa == 0 ? 8 : 4;
-    const int gw = (int)blockIdx.x * (QR_BLOCK / 64) + wv;
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (QR_BLOCK / 64) + wv);
     if (gw >= sc.n_blocks) return;
-    const u32 ord = sc.order[gw];
+    /* schedule entry {footprint coordinates, tile-list head or QR_PER_LANE_TILE}: one scalar load */
+    typedef u32 u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ sched = ((const QR_CONST u32x2_ *)sc.order)[gw];
+    const u32 ord = sched.x;
+    const int sched_head = (int)sched.y;
     const int px = fsaa == 2 ? (pix & 3) : (pix & 7), py = fsaa == 2 ? (pix >> 2) : (pix >> 3);
     const int x = (int)(ord & 0x3FFFu) * fw + px;
     const int y = (int)((ord >> 14) & 0x3FFFu) * fh + py;
     const int group = y >> 3;
 
     bool inside = x < fr->frm_w && y < fr->frm_h && y >= sc.row_begin && y < sc.row_end;
-    if (group < sc.group_first || (group - sc.group_first) % sc.group_stride != 0) inside = false;
+    if (group < sc.group_first) inside = false;
+    if (sc.group_stride != 1 && (group - sc.group_first) % sc.group_stride != 0) inside = false;
     if (inside && sc.thnum > 1) inside = (y % sc.thnum) == sc.index;
     if (!__any(inside)) return;                 /* whole wave outside this launch's rows */
 
@@ -1474,7 +1502,11 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         ray.osi = QR_NULL; ray.oflg = 0;
         ray.ploc = {0, 0, 0};
         ray.list = QR_NULL;
-        if (inside)
+        if (sched_head != QR_PER_LANE_TILE)
+        {
+            if (inside) ray.list = sched_head;
+        }
+        else if (inside)
         {
             const int tile = (y / fr->tile_h) * fr->tls_row + (x / fr->tile_w);
             ray.list = sc.tiles[tile];
@@ -1506,10 +1538,16 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         {
             Hit h; bool occ;
             QR_TICK(tk_rest);
+#ifdef QR_WAVETIME
+            const unsigned long long wt_a = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef QR_X_NOTRACE
             h.t = ray.tmax; h.si = ray.list; h.side = 0; h.loc = ray.ploc; occ = false;
 #else
             traverse<false>(sc, tr, ray, h, occ);
+#endif
+#ifdef QR_WAVETIME
+            const unsigned long long wt_b = __builtin_amdgcn_s_memrealtime();
 #endif
             QR_TICK(tk_trav);
 #ifdef QR_WAVETIME
@@ -1522,6 +1560,13 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
 
             Shaded o;
             shade<COUNT>(sc, got, ray, h, o, cnt);
+#ifdef QR_WAVETIME
+            if (__ffsll((long long)__ballot(true)) - 1 == lane)
+            {
+                unsigned long long *o_ = sc.stats + 28 + (size_t)gw * QR_WT_SLOTS;
+                o_[8] += wt_b - wt_a; o_[9] += __builtin_amdgcn_s_memrealtime() - wt_b;
+            }
+#endif
             QR_TICK(tk_shade);
 
             if (got)
@@ -1638,7 +1683,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
 #ifdef QR_WAVETIME
     if (!COUNT && __ffsll((long long)__ballot(true)) - 1 == lane)
     {
-        unsigned long long *o = counters + 32 + (size_t)gw * 4;
+        unsigned long long *o = counters + 32 + (size_t)gw * QR_WT_SLOTS;
         o[0] = wt_start; o[1] = wt_mid; o[2] = __builtin_amdgcn_s_memrealtime();
         o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))
              | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 32)

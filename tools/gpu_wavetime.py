@@ -19,7 +19,7 @@ if len(sys.argv) > 2:
 f = scn.new_frame()
 scn.render(f); torch.cuda.synchronize()
 avg, mn = scn.render_timed(f, 5)
-w = np.fromfile(out, dtype=np.uint64).reshape(-1, 4)
+w = np.fromfile(out, dtype=np.uint64).reshape(-1, 12)
 w = w[w[:, 2] != 0]
 t0 = int(w[:, 0].min())
 st = (w[:, 0].astype(np.int64) - t0) / 100.0          # us
@@ -35,6 +35,13 @@ for lo, hi in [(1, 1), (2, 3), (4, 8), (9, 1000)]:
     m = (walks >= lo) & (walks <= hi)
     if m.any():
         print(f"  walks {lo}-{hi}: {m.sum()} waves, duration mean {dur[m].mean():.1f} us max {dur[m].max():.1f}, start p50 {np.median(st[m]):.1f}, end max {en[m].max():.1f}")
+# the slowest waves: how long are their dependent chains?
+idx = np.argsort(-dur)[:8]
+for i in idx:
+    print(f"  slow wave: {dur[i]:7.1f} us start {st[i]:6.1f}  non-shadow walks {int(w[i,7])} cells {int(w[i,5])}  shadow walks {int(w[i,6])} cells {int(w[i,4])}"
+          f"  -> {dur[i]*1e3/max(1,int(w[i,4])+int(w[i,5])):.0f} ns per cell; us in traverse {int(w[i,8])/100:.1f}, shade {int(w[i,9])/100:.1f} of which shadow walks {int(w[i,10])/100:.1f}")
+tot_cells = w[:, 4].astype(np.int64) + w[:, 5].astype(np.int64)
+print(f"all waves: cells per wave mean {tot_cells.mean():.1f}; sum of wave durations / sum of cells = {dur.sum()*1e3/max(1,tot_cells.sum()):.0f} ns per cell")
 # occupancy over time: waves in flight sampled every 5% of the kernel
 T = en.max()
 for q in np.linspace(0.05, 1.0, 20):
