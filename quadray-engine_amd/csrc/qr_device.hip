@@ -735,7 +735,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
                         if (bx >= nbx || by >= nby) continue;
                         const int tlx = (bx * fw) / frm.tile_w, tly = (by * fh) / frm.tile_h;
                         const int hv = (tlx < frm.tls_row && tly < frm.tls_col) ? tile_heavy[(size_t)tly * frm.tls_row + tlx] : 0;
-                        const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14);
+                        const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14) | ((uint32_t)(hv & 3) << 30);
                         (hv ? heavy : light).push_back(ent);
                     }
         heavy.insert(heavy.end(), light.begin(), light.end());

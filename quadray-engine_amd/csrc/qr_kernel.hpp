@@ -1470,6 +1470,9 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     const u32x2_ sched = ((const QR_CONST u32x2_ *)sc.order)[gw];
     const u32 ord = sched.x;
     const int sched_head = (int)sched.y;
+    /* footprints that can recurse get issue priority: the frame ends with the slowest of them, and while
+     * the bulk is in flight they would otherwise share their SIMD's issue slots evenly */
+    if (ord >> 30) { if ((ord >> 30) >= 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
     const int px = fsaa == 2 ? (pix & 3) : (pix & 7), py = fsaa == 2 ? (pix >> 2) : (pix >> 3);
     const int x = (int)(ord & 0x3FFFu) * fw + px;
     const int y = (int)((ord >> 14) & 0x3FFFu) * fh + py;
