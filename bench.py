@@ -14,7 +14,9 @@ frames; each frame's 8-row tile rows are dealt to the N ranks in contiguous bloc
 (rotated per frame for balance), every rank renders its blocks of all N frames, then
 ONE exchange over RCCL moves the blocks so that rank f ends the step holding the
 complete frame f.  Per-GPU work is constant in N (weak scaling); the exchange runs on
-its own stream and overlaps the next step's kernels.
+its own stream and overlaps the next step's kernels.  Two steps are in flight (--inflight),
+each launch on its own HIP stream: a frame ends with a few long recursion waves, and the
+next frame's bulk fills the GPU meanwhile (frames are independent, targets double-buffered).
 
 Rays are counted by the backend's counting kernel variant (not timed): primary +
 shadow + reflection + refraction rays actually traced ("useful" rays: the backend
@@ -144,6 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="steps (frames per GPU) in flight, each on its own streams")
     args = ap.parse_args()
 
     import torch
@@ -175,25 +178,32 @@ def main():
     samples_per_frame = rc.primary
 
     ex = sharding.FrameExchange(H, W, N, rank)
-    compute = torch.cuda.Stream()
+    # --inflight steps are in flight (one render target set each), and the N row blocks of a step are independent
+    # launches: each (buffer, frame) pair has its own HIP stream, so the long recursion waves that end one
+    # launch overlap the bulk of the next instead of idling the GPU (DESIGN.md "Critical path").
+    D = max(1, args.inflight)
+    streams = [[torch.cuda.Stream() for _ in range(N)] for _ in range(D)]
+    compute = streams[0][0]
     comm = torch.cuda.Stream()
-    frames = [[scn.new_frame() for _ in range(N)] for _ in range(2)]    # double-buffered render targets
-    finals = [scn.new_frame() for _ in range(2)]                        # the frame this rank assembles
-    ev_render = [torch.cuda.Event() for _ in range(2)]
-    ev_comm = [torch.cuda.Event() for _ in range(2)]
+    frames = [[scn.new_frame() for _ in range(N)] for _ in range(D)]    # render targets of the steps in flight
+    finals = [scn.new_frame() for _ in range(D)]                        # the frame this rank assembles
+    ev_render = [[torch.cuda.Event() for _ in range(N)] for _ in range(D)]
+    ev_comm = [torch.cuda.Event() for _ in range(D)]
 
     def step(i):
-        buf = i & 1
-        with torch.cuda.stream(compute):
-            compute.wait_event(ev_comm[buf])            # the exchange that last read this buffer is done
-            for f in range(N):
+        buf = i % D
+        for f in range(N):
+            st = streams[buf][f]
+            with torch.cuda.stream(st):
+                st.wait_event(ev_comm[buf])                 # the exchange that last read this buffer is done
                 r0, r1 = ex.my_rows(f)
                 scn.set_rows(r0, r1, 0, 1)
-                scn.render(frames[buf][f], stream=compute)
-            ev_render[buf].record(compute)
+                scn.render(frames[buf][f], stream=st)
+                ev_render[buf][f].record(st)
         if N > 1:
             with torch.cuda.stream(comm):
-                comm.wait_event(ev_render[buf])
+                for f in range(N):
+                    comm.wait_event(ev_render[buf][f])
                 ex.exchange(frames[buf], finals[buf])
                 ev_comm[buf].record(comm)
 
@@ -223,7 +233,7 @@ def main():
         scn.set_rows(0, H, 0, 1)
         scn.render(whole)
         torch.cuda.synchronize()
-        ok = bool((whole == finals[(args.steps - 1) & 1]).all().item())
+        ok = bool((whole == finals[(args.steps - 1) % D]).all().item())
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -265,7 +275,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
-                       "frames_per_step": N, "rays_per_frame": rays_per_frame,
+                       "frames_per_step": N, "steps_in_flight": D, "rays_per_frame": rays_per_frame,
                        "rays": rc.as_dict(),
                        "parallelism": f"tile-row blocks x{N} + 1 exchange/step" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,

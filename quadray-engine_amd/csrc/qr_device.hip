@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <map>
+#include <array>
 #include <algorithm>
 #include <chrono>
 #include <utility>
@@ -28,15 +30,20 @@
 
 struct qr_device_scene
 {
-    int device;
-    void *d_blob;               /* one allocation holding every array      */
-    uint64_t blob_bytes;
-    DevScene sc;                /* device pointers + launch parameters      */
-    qr_frame fr;                /* host copy of the frame parameters        */
-    qr_header hdr;
-    unsigned long long *d_counters;
-    size_t n_cells;
-    hipEvent_t ev0, ev1;
+    int device = 0;
+    void *d_blob = nullptr;     /* one allocation holding every array      */
+    uint64_t blob_bytes = 0;
+    DevScene sc = {};           /* device pointers + launch parameters      */
+    qr_frame fr = {};           /* host copy of the frame parameters        */
+    qr_header hdr = {};
+    unsigned long long *d_counters = nullptr;
+    size_t n_cells = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    /* the whole-frame wave schedule (host copy) and the schedules of the row selections rendered so far:
+     * a launch restricted by qr_scene_set_rows / _set_tile_rows only starts the waves that own pixels */
+    std::vector<uint32_t> h_order;
+    struct SubSched { uint32_t *d_order; int32_t n; };
+    std::map<std::array<int32_t, 6>, SubSched> sub;
 };
 
 extern "C" const char *qr_kernel_name(void) { return "qr_render_kernel"; }
@@ -804,8 +811,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
 
-    qr_device_scene *s = new qr_device_scene();
-    memset(s, 0, sizeof(*s));
+    qr_device_scene *s = new qr_device_scene();     /* value-initialised: plain members are zero */
     s->device = device;
     s->hdr = *v.hdr;
     hipError_t e = hipMalloc(&s->d_blob, total);
@@ -833,6 +839,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->sc.bsph = (const void *)(d + o_bs);
     s->sc.order = (const uint32_t *)(d + o_ord);
     s->sc.n_blocks = (int32_t)n_sched;
+    s->h_order = order;
     s->sc.nested = nested ? 1 : 0;
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
@@ -854,6 +861,7 @@ extern "C" int qr_scene_destroy(qr_device_scene *s)
     (void)hipSetDevice(s->device);
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
+    for (auto &kv : s->sub) (void)hipFree(kv.second.d_order);
     (void)hipFree(s->d_counters);
     (void)hipFree(s->d_blob);
     delete s;
@@ -913,15 +921,60 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
     const int fsaa = s->fr.fsaa;
     const int bw = fsaa == 0 ? 32 : fsaa == 1 ? 16 : 8;
     (void)bw;
-    dim3 grid((s->sc.n_blocks + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64), 1, 1);
-    if (grid.x == 0 || s->sc.n_groups == 0) return hipSuccess;
+    if (s->sc.n_groups == 0) return hipSuccess;
+    DevScene sc = s->sc;
+    const int H = s->fr.frm_h;
+    const bool whole = sc.row_begin == 0 && sc.row_end == H && sc.group_first == 0 && sc.group_stride == 1 && sc.thnum <= 1;
+    if (!whole)
+    {
+        const std::array<int32_t, 6> key = { sc.row_begin, sc.row_end, sc.group_first, sc.group_stride, sc.index, sc.thnum };
+        auto it = s->sub.find(key);
+        if (it == s->sub.end())
+        {
+            /* first launch with this selection: keep the schedule entries whose footprint holds a selected row */
+            const int fh = fsaa == 0 ? 8 : 4;
+            std::vector<uint32_t> keep;
+            for (size_t i = 0; i + 1 < s->h_order.size(); i += 2)
+            {
+                const int y0 = (int)((s->h_order[i] >> 14) & 0x3FFFu) * fh;
+                bool any = false;
+                for (int y = y0; y < y0 + fh && y < H && !any; y++)
+                {
+                    const int g = y >> 3;
+                    any = y >= sc.row_begin && y < sc.row_end && g >= sc.group_first && (g - sc.group_first) % sc.group_stride == 0
+                       && (sc.thnum <= 1 || (y % sc.thnum) == sc.index);
+                }
+                if (any) { keep.push_back(s->h_order[i]); keep.push_back(s->h_order[i + 1]); }
+            }
+            if (s->sub.size() >= 256)
+            {
+                /* a selection is still in use by queued launches: wait before recycling the buffers */
+                (void)hipDeviceSynchronize();
+                for (auto &kv : s->sub) (void)hipFree(kv.second.d_order);
+                s->sub.clear();
+            }
+            qr_device_scene::SubSched ss = { nullptr, (int32_t)(keep.size() / 2) };
+            if (ss.n > 0)
+            {
+                hipError_t e = hipMalloc((void **)&ss.d_order, keep.size() * 4);
+                if (e != hipSuccess) return e;
+                e = hipMemcpy(ss.d_order, keep.data(), keep.size() * 4, hipMemcpyHostToDevice);
+                if (e != hipSuccess) { (void)hipFree(ss.d_order); return e; }
+            }
+            it = s->sub.emplace(key, ss).first;
+        }
+        sc.order = it->second.d_order;
+        sc.n_blocks = it->second.n;
+    }
+    dim3 grid((sc.n_blocks + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64), 1, 1);
+    if (grid.x == 0) return hipSuccess;
     /* register budget variant (waves per SIMD); QR_WAVES is a tuning knob for experiments */
     static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
                                     return (w == 2 || w == 3 || w == 4) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
-    if (waves == 4)      hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
-    else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<COUNT, 3>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
-    else                 hipLaunchKernelGGL((qr_render_kernel<COUNT, 2>), grid, dim3(QR_BLOCK), 0, st, s->sc, f, ids_dev, s->d_counters);
+    if (waves == 4)      hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
+    else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<COUNT, 3>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
+    else                 hipLaunchKernelGGL((qr_render_kernel<COUNT, 2>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     return hipGetLastError();
 }
 
