@@ -51,6 +51,13 @@
 #ifndef QR_MAX_DEPTH
 #define QR_MAX_DEPTH 10           /* RT_STACK_DEPTH, tracer.h:46 */
 #endif
+/* timing experiments (QR_DBG environment variable) exist only in -DQR_KNOBS builds: every knob the
+ * production kernel tests costs a hoisted SGPR pair, and the allocator is already spilling SGPRs */
+#ifdef QR_KNOBS
+#define QR_KNOB(bit) ((sc.dbg & (bit)) != 0)
+#else
+#define QR_KNOB(bit) false
+#endif
 #define QR_PER_LANE_TILE (-2) /* schedule entry: the footprint straddles tiles, look the list up per pixel */
 #define QR_WT_SLOTS 12       /* QR_WAVETIME builds: u64 slots per wave */
 #ifndef QR_PIPE
@@ -648,7 +655,7 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
             }
             else
             {
-                const int solver = (SHADOW && (sc.dbg & 32)) ? 0 : (int)DF_SOLVER(fl);
+                const int solver = (SHADOW && QR_KNOB(32)) ? 0 : (int)DF_SOLVER(fl);
                 /* up to two candidate roots per lane, in the lane's own order */
                 float ct0 = 0.0f, ct1 = 0.0f;
                 int   cs0 = 0, cs1 = 0;
@@ -775,7 +782,7 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
                     const float t = p == 0 ? ct0 : ct1;
                     const int side = p == 0 ? cs0 : cs1;
                     u32 m = ((p == 0 ? cm0 : cm1) && !done) ? 0xFFFFFFFFu : 0u;
-                    if (!__any(m != 0) || (SHADOW && (sc.dbg & 16))) continue;
+                    if (!__any(m != 0) || (SHADOW && QR_KNOB(16))) continue;
                     V3 loc;
                     m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc
 #ifdef QR_STATS2
@@ -841,7 +848,9 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
     const SrfP D = c_srf(sc);
     int e = __builtin_amdgcn_readfirstlane(head);
     const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
-    const float dlen = __builtin_sqrtf(dd);
+    /* only the cull uses the ray length: an upper bound is enough there, so the 1-instruction
+     * approximate square root (1 ulp) inflated by 2^-20 replaces the IEEE expansion */
+    const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0, st_skip = 0;
 #endif
@@ -881,7 +890,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
          */
         bool skip = false;
         int jump = QR_NULL;
-        if ((el.kind & 4) && !(sc.dbg & (SHADOW ? 64 : 128)))
+        if ((el.kind & 4) && !QR_KNOB(SHADOW ? 64 : 128))
         {
             const float R = cs.r;
             const float ocx = cs.cx - r.org.x, ocy = cs.cy - r.org.y, ocz = cs.cz - r.org.z;
@@ -1157,8 +1166,8 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         sr.list = el.data; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
         Hit sh; bool occ;
         if (COUNT) { if (lm) cnt.shadow++; }
-        if (sc.dbg & 2) lm = false;
-        if (sc.dbg & 1) occ = false; else
+        if (QR_KNOB(2)) lm = false;
+        if (QR_KNOB(1)) occ = false; else
         {
 #ifdef QR_X_NOSHADOW
             occ = false; sh.si = 0;
@@ -1557,7 +1566,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
             if (wt_mid == 0) wt_mid = __builtin_amdgcn_s_memrealtime();
             wt_push++;
 #endif
-            const bool got = tr && h.si != QR_NULL && !(sc.dbg & 4);
+            const bool got = tr && h.si != QR_NULL && !QR_KNOB(4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
             if (got && sp == 0) hit_id = (h.si << 1) | h.side;
 
