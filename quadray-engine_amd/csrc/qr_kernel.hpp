@@ -1718,6 +1718,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     {
         if (fr->ctx_flags & QR_PROP_GAMMA)
         {
+            asm volatile("" ::: "memory");      /* keep the branch: three IEEE square roots are not worth speculating */
             cr = __builtin_sqrtf(cr); cg = __builtin_sqrtf(cg); cb = __builtin_sqrtf(cb);
         }
         cr = cr * fr->clamp; cg = cg * fr->clamp; cb = cb * fr->clamp;
