@@ -60,9 +60,6 @@
 #endif
 #define QR_PER_LANE_TILE (-2) /* schedule entry: the footprint straddles tiles, look the list up per pixel */
 #define QR_WT_SLOTS 12       /* QR_WAVETIME builds: u64 slots per wave */
-#ifndef QR_PIPE
-#define QR_PIPE 0                 /* list-walk prefetch depth: 0 none, 1 next cell, 2 next cell + next record */
-#endif
 #ifndef QR_MIN_WAVES_PER_SIMD
 #define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
 #endif
@@ -223,22 +220,6 @@ __device__ __forceinline__ CellS ld_cell(ElmP p)
     return c;
 }
 
-/* the hot part of a surface record, held in SGPRs */
-struct SV
-{
-    SrfP p;                         /* fields are scalar-loaded where they are used:
-                                       holding all 20 hot dwords in SGPRs at once costs
-                                       ~130 SGPR spills (measured slower) */
-};
-
-__device__ __forceinline__ SV ld_hot(SrfP p)
-{
-    SV s;
-    s.p = p;
-    return s;
-}
-
-__device__ __forceinline__ float sci_at(const SV &s, int i) { return i == 0 ? s.p->sci[0] : i == 1 ? s.p->sci[1] : s.p->sci[2]; }
 
 /* 3x3 transform, tracer.cpp:1447-1479 order; matrix rows come from the cold part */
 __device__ __forceinline__ V3 xform(SrfP p, int has_trm, V3 in)
@@ -339,7 +320,7 @@ __device__ __forceinline__ float hsci(const Hot &s, int i)
 /* ------------------------------------------------------------------------ */
 
 __device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
-                                     const Ray &r, const Walk &w, const V3 &ry, const V3 &df,
+                                     const Ray &r, const Walk &w, const V3 &df,
                                      bool dmask, u32 amask, float t, int side, u32 m, V3 &loc
 #ifdef QR_STATS2
                                      , unsigned long long *g_clip
@@ -784,7 +765,7 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
                     u32 m = ((p == 0 ? cm0 : cm1) && !done) ? 0xFFFFFFFFu : 0u;
                     if (!__any(m != 0) || (SHADOW && QR_KNOB(16))) continue;
                     V3 loc;
-                    m = clip(sc, s, P, r, w, ry, df, dmask, amask, t, side, m, loc
+                    m = clip(sc, s, P, r, w, df, dmask, amask, t, side, m, loc
 #ifdef QR_STATS2
                              , g_seg + 4
 #endif
