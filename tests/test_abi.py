@@ -59,3 +59,34 @@ def test_flatten_rejects_bad_abi(qr):
     blob = ctypes.c_void_p(); size = ctypes.c_uint64()
     rc = L.qr_flatten(dummy, ctypes.byref(abi), ctypes.byref(blob), ctypes.byref(size))
     assert rc == -2
+
+
+def test_upload_rejects_oversized_frame_and_broken_lists(qr):
+    """Limits are checked on the host before anything touches a device: a frame wider than the wave
+    schedule can address, a cyclic list and an array that ends outside its list are refused with an
+    argument error (also on a machine without a GPU, where a well-formed scene fails with a device error)."""
+    import importlib.util, struct
+    spec = importlib.util.spec_from_file_location("qr_synth", os.path.join(ROOT, "quadray-engine_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
+    L = qr.lib()
+
+    def err_of(blob):
+        h = ctypes.c_void_p(); buf = ctypes.create_string_buffer(blob, len(blob))
+        rc = L.qr_scene_upload(buf, len(blob), 0, ctypes.byref(h))
+        if rc == 0:
+            L.qr_scene_destroy(h)
+        return rc, L.qr_last_error().decode()
+
+    rc, msg = err_of(synth.make_scene(n_objects=8, width=8 * 16384 + 8, height=8, depth=1, box=8.0))
+    assert rc == -1 and "too large" in msg
+    good = bytearray(synth.make_scene(n_objects=8, width=64, height=48, depth=1, box=8.0))
+    off_elm = struct.unpack_from("<I", good, 4 * 14)[0]
+    cyc = bytearray(good)
+    off_frame = struct.unpack_from("<I", cyc, 4 * 10)[0]
+    head = struct.unpack_from("<i", cyc, off_frame + 4 * 38)[0]             # qr_frame.clist
+    e = head
+    while struct.unpack_from("<i", cyc, off_elm + 16 * e + 8)[0] != -1:
+        e = struct.unpack_from("<i", cyc, off_elm + 16 * e + 8)[0]
+    struct.pack_into("<i", cyc, off_elm + 16 * e + 8, head)                 # last cell's next -> head
+    rc, msg = err_of(bytes(cyc))
+    assert rc == -1 and "cyclic" in msg, msg

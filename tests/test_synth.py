@@ -89,3 +89,29 @@ def test_gpu_synth_10k_full_size_properties(qr):
     assert (other.info.tile_w, other.info.tile_h) == (16, 16)
     f2 = other.render(); torch.cuda.synchronize()
     assert bool((f2 == whole).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,fsaa", [(1, 1, 0), (7, 5, 0), (33, 17, 2), (100, 3, 0), (9, 64, 2), (257, 31, 0)])
+def test_gpu_ragged_frames_match_oracle(qr, oracle, w, h, fsaa):
+    """Frame sizes that are not multiples of the wave footprint (8x8, 4x4 with FSAA) or of the tile size,
+    down to a single pixel; with and without the GPU binning pass."""
+    import torch
+    blob = _synth().make_scene(n_objects=40, width=w, height=h, depth=3, box=8.0, fsaa=fsaa, gamma=bool(fsaa))
+    o_frame, _, _ = oracle.render(blob, threads=4)
+    for rebin in (False, True):
+        scn = qr.Scene(blob, rebin_tiles=rebin)
+        f = scn.render(); torch.cuda.synchronize()
+        assert (f.cpu().numpy().view(np.uint32) == o_frame).all(), f"rebin={rebin}"
+
+
+@pytest.mark.gpu
+def test_gpu_scene_without_objects(qr, oracle):
+    """Only the ground plane: every list is one cell long, most tiles are empty."""
+    import torch
+    blob = _synth().make_scene(n_objects=0, width=64, height=48, depth=4, box=10.0)
+    o_frame, _, counts = oracle.render(blob, threads=2)
+    assert counts["reflect"] == 0 and counts["refract"] == 0
+    for rebin in (False, True):
+        f = qr.Scene(blob, rebin_tiles=rebin).render(); torch.cuda.synchronize()
+        assert (f.cpu().numpy().view(np.uint32) == o_frame).all()
