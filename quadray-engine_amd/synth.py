@@ -10,7 +10,8 @@ scenes), materials, lights, and the surface lists:
     median-split bounding-sphere tree written depth-first as nested arrays -- the reference's
     array/bounding-volume list format (tracer.cpp:3955-4054, elm_DATA = last element of the sub-list)
     is a flattened BVH with skip links;
-  * one light list shared by all surfaces;
+  * per object and light a short flat shadow list of the objects that can stand between the two (what
+    the engine's ssort/lsort builds with bbox_shad), the global list for the ground plane;
   * NO tile lists: the snapshot has a single whole-frame tile pointing at the camera list, and the
     backend builds per-tile lists with its GPU binning pass (QR_UPLOAD_REBIN_TILES).
 
@@ -118,9 +119,10 @@ class _Builder:
 
 
 def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, box=100.0, gamma=False, fsaa=0,
-               hierarchy=True, leaf=16):
+               hierarchy=True, leaf=16, shadow_lists=True):
     """Return the snapshot bytes of the synthetic scene.  hierarchy=False writes one flat list without
-    bounding-volume elements (same image, used by the tests to check that the volumes are conservative)."""
+    bounding-volume elements (same image, used by the tests to check that the volumes are conservative);
+    shadow_lists=False gives every object the global list as shadow list (same image, slower)."""
     rng = _Rng(seed)
     b = _Builder()
 
@@ -226,11 +228,38 @@ def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, bo
         top_cells += [b.cell(o[0]) for o in obj]
     glist = b.link(top_cells)
 
-    # one light list for everything; every light's shadow list is the global list
+    # light lists.  Default: one light list for everything, every light's shadow list is the global list.
     llist = b.link([b.cell(l, data=glist) for l in lights])
     for r in b.srf:
         if int(r[37]) < TAG_BOUND:
             r[44:48] = np.array([llist, glist, llist, glist], dtype=np.int32).view(np.uint32)
+    if shadow_lists and obj:
+        # Per object and light, the engine's kind of shadow list (ssort/lsort + bbox_shad, engine.cpp:2134-2753):
+        # only the objects that can stand between the light and this object -- those whose bounding sphere
+        # meets the cone from the light over the object's bounding sphere (the object itself included: an
+        # open quadric can shadow its own inside).  Flat lists: they are short.  The ground plane keeps
+        # the global hierarchical list.
+        cen = np.array([o[1] for o in obj]); rad_b = np.array([o[2] for o in obj])
+        lpos = np.array([b.lgt[l].view(np.float32)[1:4] for l in lights], dtype=np.float64)
+        heads = np.full((len(obj), len(lights)), NULL, dtype=np.int64)
+        for li in range(len(lights)):
+            P = cen - lpos[li]                                   # light -> every object
+            P2 = (P * P).sum(1)
+            for c0 in range(0, len(obj), 256):                   # 256 cone axes at a time against all objects
+                d = P[c0:c0 + 256]; D2 = P2[c0:c0 + 256]; D = np.sqrt(D2); r = rad_b[c0:c0 + 256]
+                Pd = d @ P.T                                     # [axis, object]
+                t = Pd / D2[:, None]
+                tc = np.clip(t, 0.0, 1.0)
+                dist2 = np.maximum(P2[None, :] - 2.0 * tc * Pd + tc * tc * D2[:, None], 0.0)
+                reach = (rad_b[None, :] + r[:, None] * tc) * 1.05 + 1e-3
+                hit = (dist2 <= reach * reach) & (t <= 1.0 + (r[:, None] + rad_b[None, :]) / D[:, None] * 1.05 + 1e-3) \
+                    & (t >= -rad_b[None, :] / D[:, None] - 1e-3)
+                hit[np.arange(len(d)), np.arange(c0, c0 + len(d))] = True
+                for j in range(len(d)):
+                    heads[c0 + j, li] = b.link([b.cell(obj[y][0]) for y in np.nonzero(hit[j])[0]])
+        for k, (s, c, r) in enumerate(obj):
+            ll = b.link([b.cell(l, data=int(heads[k, li])) for li, l in enumerate(lights)])
+            b.srf[s][44] = np.uint32(ll & 0xFFFFFFFF); b.srf[s][46] = np.uint32(ll & 0xFFFFFFFF)
 
     # ---- camera: outside a corner of the box, looking at its centre ------------------------------
     eye = np.array([-0.95 * box, -1.25 * box, 0.9 * box + 1.5])
