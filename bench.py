@@ -49,6 +49,12 @@ WORKLOADS = {
     "demo2_2160p_aa4": ("c4_demo02_2160p_aa4_gf",
                         ["--scene", "demo02", "-w", "3840", "-h", "2160", "--gamma", "--fresnel", "--fsaa", "4"],
                         "demo scene 2 @3840x2160, 4x FSAA, Gamma+Fresnel"),
+    # BASELINE.json config 5: not a reference scene (quadray-engine_amd/synth.py builds the snapshot, the GPU
+    # binning pass its tile lists); the CPU baseline is the oracle port on a sample of rows
+    "synth10k_4320p": ("synth:10000:7680:4320:4", None,
+                       "synthetic 10 000 quadrics @7680x4320, depth 4, 4 lights (quadray-engine_amd/synth.py)"),
+    "synth10k_1080p": ("synth:10000:1920:1080:4", None,
+                       "synthetic 10 000 quadrics @1920x1080, depth 4, 4 lights (quadray-engine_amd/synth.py)"),
 }
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -74,7 +80,18 @@ def measured_valu(workload):
         return None
 
 
+_SYNTH_CACHE = {}
+
+
 def load_blob(name):
+    if name.startswith("synth:"):
+        if name not in _SYNTH_CACHE:
+            n, w, h, d = (int(x) for x in name.split(":")[1:])
+            spec = importlib.util.spec_from_file_location("qr_synth", os.path.join(ROOT, "quadray-engine_amd", "synth.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _SYNTH_CACHE[name] = mod.make_scene(n_objects=n, width=w, height=h, depth=d)
+        return _SYNTH_CACHE[name]
     with open(os.path.join(ROOT, "tests", "golden", name + ".qrs.gz"), "rb") as f:
         return gzip.decompress(f.read())
 
@@ -104,6 +121,20 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
     cores = min(os.cpu_count() or 1, 16)
     ref = os.path.join(ROOT, "oracle", "_ref", "qr_ref")
     snap, ref_args, _ = WORKLOADS[workload]
+    if ref_args is None:
+        # no reference scene: the oracle port on a horizontal band of the frame, rays counted by the oracle
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import qr_oracle
+        blob = load_blob(snap)
+        h = qr_oracle.info(blob)["h"]
+        rows = 8
+        t0 = time.time(); _, _, c = qr_oracle.render(blob, threads=cores, rows=(h // 2, h // 2 + rows), deferred=True); dt = time.time() - t0
+        rows = int(max(8, min(h // 2, rows * frames_budget_s / max(dt, 1e-3)))) // 8 * 8
+        t0 = time.time(); _, _, c = qr_oracle.render(blob, threads=cores, rows=(h // 2 - rows // 2, h // 2 - rows // 2 + rows), deferred=True); dt = time.time() - t0
+        rays = c["primary"] + c["shadow"] + c["reflect"] + c["refract"]
+        return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                    sample=f"{rows} rows around the middle of the frame with oracle/qr_oracle.c (scalar C + OpenMP, {cores} threads): "
+                           f"{rays} rays in {dt:.2f} s")
     if os.path.exists(ref):
         try:
             import tempfile
@@ -167,7 +198,7 @@ def main():
 
     snap, _, desc = WORKLOADS[args.workload]
     blob = load_blob(snap)
-    scn = qr.Scene(blob, device=local_rank)
+    scn = qr.Scene(blob, device=local_rank, rebin_tiles=snap.startswith("synth:"))
     W, H = scn.width, scn.height
     n_groups = (H + 7) // 8
     N = world
