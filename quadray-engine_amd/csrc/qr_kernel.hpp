@@ -873,17 +873,18 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         int jump = QR_NULL;
         if ((el.kind & 4) && !QR_KNOB(SHADOW ? 64 : 128))
         {
+            /* not reference arithmetic: fused operations are fine here.  The line misses the sphere iff
+             * b^2 < dd * (|oc|^2 - R^2); 1e-5 * |oc|^2 * dd on the left absorbs the rounding of both
+             * sides (a few 1e-7 relative to |oc|^2 * dd), on top of the inflated radius. */
             const float R = cs.r;
             const float ocx = cs.cx - r.org.x, ocy = cs.cy - r.org.y, ocz = cs.cz - r.org.z;
-            const float b = ocx * r.dir.x + ocy * r.dir.y + ocz * r.dir.z;
-            const float crx = ocy * r.dir.z - ocz * r.dir.y;
-            const float cry = ocz * r.dir.x - ocx * r.dir.z;
-            const float crz = ocx * r.dir.y - ocy * r.dir.x;
+            const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+            const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
             const float R2 = R * R;
-            const u32 outside = LM((ocx * ocx + ocy * ocy + ocz * ocz) > 1.01f * R2);
-            const u32 miss = LM((crx * crx + cry * cry + crz * crz) > dd * R2)
-                           | (outside & LM(b < 0.0f))
-                           | LM((b - R * dlen) > w.tbuf * dd);
+            const float q = oc2 - R2;
+            const u32 outside = LM(q > 0.01f * R2);
+            const u32 miss = (outside & (LM(__builtin_fmaf(oc2 * dd, 1e-5f, b * b) < dd * q) | LM(b < 0.0f)))
+                           | LM(__builtin_fmaf(-R, dlen, b) > w.tbuf * dd);
             const u32 need = LM(live && w.resume == QR_NULL) & ~(miss & LM(el.simd != r.osi));
             skip = !__any(need != 0);
         }
