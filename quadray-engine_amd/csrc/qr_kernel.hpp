@@ -1474,6 +1474,23 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
     if (sc.group_stride != 1 && (group - sc.group_first) % sc.group_stride != 0) inside = false;
     if (inside && sc.thnum > 1) inside = (y % sc.thnum) == sc.index;
     if (!__any(inside)) return;                 /* whole wave outside this launch's rows */
+    if (sched_head == QR_NULL)
+    {
+        /* empty tile: no ray of the footprint meets anything; the reference's pipeline ends with
+         * colour 0 for such a packet (clamp, sqrt and cvt of 0 are 0), so store it and leave */
+        if (inside && k == 0)
+        {
+            frame[(size_t)y * fr->frm_w + x] = 0u;
+            if (ids != nullptr) ids[(size_t)y * fr->frm_w + x] = -1;
+        }
+        if (COUNT)
+        {
+            unsigned long long n = inside ? 1ull : 0ull;
+            for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+            if (lane == 0 && n != 0) atomicAdd(&counters[0], n);
+        }
+        return;
+    }
 
     Counters cnt = {0, 0, 0, 0};
 
