@@ -1500,8 +1500,11 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
         int ai = 0;
         if (fsaa == 1) ai = (x & 1) * 2 + k;
         if (fsaa == 2) ai = k;
-        float hs = (float)x + fr->hor_a[ai]; hs = hs + 0.0f;
-        float vs = (float)y + fr->ver_a[ai]; vs = vs + 0.0f;
+        float ha, va;
+        if (fsaa == 0) { ha = fr->hor_a[0]; va = fr->ver_a[0]; }       /* wave-uniform: scalar loads */
+        else { ha = ((const float *)sc.frp->hor_a)[ai]; va = ((const float *)sc.frp->ver_a)[ai]; }
+        float hs = (float)x + ha; hs = hs + 0.0f;
+        float vs = (float)y + va; vs = vs + 0.0f;
         float x1 = fr->hor[0] * hs, x2 = fr->hor[1] * hs, x3 = fr->hor[2] * hs;
         float x4 = fr->ver[0] * vs, x5 = fr->ver[1] * vs, x6 = fr->ver[2] * vs;
         x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
