@@ -82,6 +82,50 @@ static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
         hi[k] = (q.minmax_t & (1u << (3 + k))) ? (double)q.max[k] : INF;
         if (lo[k] > hi[k]) { lo[k] = hi[k] = 0.5 * (lo[k] + hi[k]); }    /* empty box: nothing visible */
     }
+    /*
+     * Custom clippers that bound the surface (engine.cpp:1845-1947 builds the list, tracer.cpp:1931-2151
+     * applies it): a clipper kept on its inner side (data > 0: f <= 0) that is a closed quadric confines the
+     * surface to that quadric's box; a plane clipper to a half-space.  Only untransformed pairs outside
+     * accumulator segments are used -- ignoring a clipper is always conservative.
+     */
+    if (q.has_trm == 0 && q.clip != QR_NULL)
+    {
+        bool plain = true;
+        int guard = 0;
+        for (int e = q.clip; e != QR_NULL && plain; e = v.elm[e].next)
+            if (v.elm[e].simd == QR_NULL || ++guard > 4096) plain = false;
+        for (int e = q.clip; e != QR_NULL && plain; e = v.elm[e].next)
+        {
+            const qr_elem &ce = v.elm[e];
+            if (ce.simd < 0 || ce.simd >= (int)v.hdr->n_srf) continue;
+            const qr_surface &c = v.srf[ce.simd];
+            if (c.has_trm != 0 || c.srf_t[3] < 0 || c.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+            if (c.srf_t[2] == 1)
+            {
+                /* PL_clp 4198-4208: f = +-(x_a - pos_a); APPLY_CLIP: data < 0 keeps f >= 0, data > 0 keeps f <= 0 */
+                const int a = (int)((c.axes >> 4) & 3);
+                if (a > 2) continue;
+                const bool neg = ((c.axes >> 10) & 1) != 0;
+                const double lim = (double)c.pos[a] - (double)q.pos[a];
+                const bool keep_le = (ce.data > 0) != neg;      /* x_a <= pos_a survives */
+                if (keep_le) { if (hi[a] > lim + 1e-4) hi[a] = lim + 1e-4; }
+                else         { if (lo[a] < lim - 1e-4) lo[a] = lim - 1e-4; }
+            }
+            else if ((c.srf_t[2] == 2 || c.srf_t[2] == 3) && ce.data > 0 &&
+                     c.sci[0] > 0.0f && c.sci[1] > 0.0f && c.sci[2] > 0.0f && c.sci[3] > 0.0f &&
+                     (c.srf_t[2] == 3 || (c.scj[0] == 0.0f && c.scj[1] == 0.0f && c.scj[2] == 0.0f)))
+            {
+                for (int a = 0; a < 3; a++)
+                {
+                    const double ext = __builtin_sqrt((double)c.sci[3] / (double)c.sci[a]) * 1.0005 + 1e-4;
+                    const double cl = (double)c.pos[a] - (double)q.pos[a];
+                    if (lo[a] < cl - ext) lo[a] = cl - ext;
+                    if (hi[a] > cl + ext) hi[a] = cl + ext;
+                }
+            }
+        }
+        for (int k = 0; k < 3; k++) if (lo[k] > hi[k]) { lo[k] = hi[k] = 0.5 * (lo[k] + hi[k]); }
+    }
     const int solver = q.srf_t[0];
     if (solver == 1)
     {
@@ -328,11 +372,8 @@ static bool screen_interval(double a, double z, double R, double c_pix, double p
 static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph, qr_frame &frm,
                        std::vector<qr_elem> &E, std::vector<int32_t> &T)
 {
-    if ((int)v.hdr->n_tiles <= 1)
-    {
-        frm.tile_w = 32; frm.tile_h = 8;                        /* RT_TILE_W, RT_TILE_H: engine.h:38-39 */
-        if (const char *ts = getenv("QR_BIN_TILE")) { int w = 0, h = 0; if (sscanf(ts, "%dx%d", &w, &h) == 2 && w > 0 && h > 0) { frm.tile_w = w; frm.tile_h = h; } }
-    }
+    if ((int)v.hdr->n_tiles <= 1) { frm.tile_w = 32; frm.tile_h = 8; }    /* RT_TILE_W, RT_TILE_H: engine.h:38-39 */
+    if (const char *ts = getenv("QR_BIN_TILE")) { int w = 0, h = 0; if (sscanf(ts, "%dx%d", &w, &h) == 2 && w > 0 && h > 0) { frm.tile_w = w; frm.tile_h = h; } }
     frm.tls_row = (frm.frm_w + frm.tile_w - 1) / frm.tile_w;
     frm.tls_col = (frm.frm_h + frm.tile_h - 1) / frm.tile_h;
     const int n_tiles = frm.tls_row * frm.tls_col;
