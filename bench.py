@@ -191,10 +191,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("QR_BENCH_SAME_DEVICE"):          # rehearsal of the N > 1 code path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("QR_BENCH_SAME_DEVICE"):
+            dist.init_process_group("gloo")              # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     snap, _, desc = WORKLOADS[args.workload]
     blob = load_blob(snap)

@@ -52,6 +52,11 @@ class FrameExchange:
         if world == 1:
             final.copy_(frames[0])
             return
+        # gloo has no device-memory send/recv: stage through host memory (CPU tests, one-GPU rehearsals)
+        staged = final.is_cuda and dist.get_backend(group) == "gloo"
+        if staged:
+            torch.cuda.current_stream().synchronize()
+            recv_host = {}
         ops, keep = [], []
         for peer in range(world):
             sb = block_of(rank, peer, world)            # my block of frame `peer` goes to rank `peer`
@@ -61,6 +66,10 @@ class FrameExchange:
             if peer == rank:
                 dst.copy_(src)
                 continue
+            if staged:
+                src = src.cpu()
+                recv_host[peer] = (torch.empty(dst.shape, dtype=dst.dtype), dst)
+                dst = recv_host[peer][0]
             if src.numel():
                 ops.append(dist.P2POp(dist.isend, src, peer, group))
             if dst.numel():
@@ -69,3 +78,6 @@ class FrameExchange:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if staged:
+            for host, dev in recv_host.values():
+                dev.copy_(host)
