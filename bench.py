@@ -141,19 +141,29 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
             tmp = tempfile.mkdtemp(prefix="qrbench_")
             os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
 
-            def run(n):
-                out = subprocess.run([ref] + ref_args + ["--threads", str(cores), "--bench", str(n)],
+            def run(n, threads):
+                out = subprocess.run([ref] + ref_args + ["--threads", str(threads), "--bench", str(n)],
                                      cwd=tmp, capture_output=True, text=True, timeout=300)
                 line = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0].split()
                 head = out.stdout.splitlines()[0]
                 return float(line[line.index("median_ms") + 1]), head
-            ms, _ = run(3)                      # calibrate, then fill the time budget
+            ms, _ = run(3, cores)               # calibrate, then fill the time budget
             n = int(max(5, min(3000, frames_budget_s * 1000.0 / max(ms, 0.01))))
-            ms, head = run(n)
+            ms, head = run(n, cores)
             simd = head.split("simd ")[1].split()[0] if "simd " in head else "auto"
-            return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="reference",
-                        sample=f"{n} frames of the same workload through the unmodified reference's rt_Scene::render "
-                               f"(update phases included, SIMD target {simd}, {cores} threads), median {ms:.3f} ms/frame")
+            res = dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="reference",
+                       sample=f"{n} frames of the same workload through the unmodified reference's rt_Scene::render "
+                              f"(update phases included, SIMD target {simd}, {cores} threads), median {ms:.3f} ms/frame")
+            try:
+                # the same binary on ONE host thread (the reference's default RooT/core_test configuration), ~5 s
+                ms1, _ = run(3, 1)
+                n1 = int(max(5, min(1000, 5000.0 / max(ms1, 0.01))))
+                ms1, _ = run(n1, 1)
+                res["single_thread"] = dict(value=rays_per_frame / ms1 / 1e3, unit="Mrays/s", cores=1,
+                                            sample=f"{n1} frames, median {ms1:.3f} ms/frame")
+            except Exception as e:
+                print(f"single-thread baseline failed: {e}", file=sys.stderr)
+            return res
         except Exception as e:  # fall through to the port
             print(f"reference baseline failed: {e}", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
