@@ -41,6 +41,7 @@ struct qr_device_scene
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* the whole-frame wave schedule (host copy) and the schedules of the row selections rendered so far:
      * a launch restricted by qr_scene_set_rows / _set_tile_rows only starts the waves that own pixels */
+    bool divergent = false;     /* launch the per-lane (divergent) walk variant, see walk_div */
     std::vector<uint32_t> h_order;
     struct SubSched { uint32_t *d_order; int32_t n; };
     std::map<std::array<int32_t, 6>, SubSched> sub;
@@ -882,6 +883,19 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->sc.n_blocks = (int32_t)n_sched;
     s->h_order = order;
     s->sc.nested = nested ? 1 : 0;
+    {
+        /* Divergent variant: for scenes of very many small objects, where the rays of a wave share little.
+         * It has no custom-clipper loop, so scenes with clip lists never take it.  QR_DIV=0|1 overrides. */
+        bool any_clip = false; int n_real = 0;
+        for (int i = 0; i < n_srf; i++)
+        {
+            const qr_surface &q = v.srf[i];
+            if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
+            n_real++; if (q.clip != QR_NULL) any_clip = true;
+        }
+        const char *dv = getenv("QR_DIV");
+        s->divergent = !any_clip && (dv ? atoi(dv) != 0 : n_real >= 1024);
+    }
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
     s->fr = frm;
@@ -1013,7 +1027,8 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
     static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
                                     return (w == 2 || w == 3 || w == 4) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
-    if (waves == 4)      hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
+    if (s->divergent)    hipLaunchKernelGGL((qr_render_kernel<COUNT, 4, true>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
+    else if (waves == 4) hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<COUNT, 3>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     else                 hipLaunchKernelGGL((qr_render_kernel<COUNT, 2>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     return hipGetLastError();

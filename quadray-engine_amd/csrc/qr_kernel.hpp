@@ -222,7 +222,8 @@ __device__ __forceinline__ CellS ld_cell(ElmP p)
 
 
 /* 3x3 transform, tracer.cpp:1447-1479 order; matrix rows come from the cold part */
-__device__ __forceinline__ V3 xform(SrfP p, int has_trm, V3 in)
+template <typename SP>
+__device__ __forceinline__ V3 xform(SP p, int has_trm, V3 in)
 {
     float x4 = p->tci[0] * in.x;
     float x5 = p->tcj[1] * in.y;
@@ -299,6 +300,19 @@ __device__ __forceinline__ Hot ld_hot5(SrfP p)
     h.max0 = u2f(e.x); h.max1 = u2f(e.y); h.max2 = u2f(e.z); h.t_eps = u2f(e.w);
     return h;
 }
+/* the same for a per-lane surface (divergent walk): five 16-byte vector loads */
+__device__ __forceinline__ Hot ld_hot5(const DSurf *p)
+{
+    const u32x4 *q = (const u32x4 *)p;
+    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    Hot h;
+    h.pos0 = u2f(a.x); h.pos1 = u2f(a.y); h.pos2 = u2f(a.z); h.flags = a.w;
+    h.sci0 = u2f(b.x); h.sci1 = u2f(b.y); h.sci2 = u2f(b.z); h.sci3 = u2f(b.w);
+    h.scj0 = u2f(c.x); h.scj1 = u2f(c.y); h.scj2 = u2f(c.z); h.clip = (int)c.w;
+    h.min0 = u2f(d.x); h.min1 = u2f(d.y); h.min2 = u2f(d.z); h.d_eps = u2f(d.w);
+    h.max0 = u2f(e.x); h.max1 = u2f(e.y); h.max2 = u2f(e.z); h.t_eps = u2f(e.w);
+    return h;
+}
 #pragma clang diagnostic pop
 
 /* sci[axis] for a wave-uniform axis: scalar bit-select (a ternary chain over the
@@ -319,7 +333,8 @@ __device__ __forceinline__ float hsci(const Hot &s, int i)
 /* local hit (ctx_NEW_* of the surface's space).                             */
 /* ------------------------------------------------------------------------ */
 
-__device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
+template <bool DIV, typename SP>
+__device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SP P,
                                      const Ray &r, const Walk &w, const V3 &df,
                                      bool dmask, u32 amask, float t, int side, u32 m, V3 &loc
 #ifdef QR_STATS2
@@ -423,6 +438,7 @@ __device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
 #endif
     /* custom clipping, 1931-2151 */
     int e = s.clip;
+    if (DIV) e = QR_NULL;        /* the divergent kernel is only launched for scenes without custom clippers */
     if (e != QR_NULL && __any(m != 0))
     {
         int redx = QR_NULL;
@@ -537,8 +553,8 @@ __device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SrfP P,
 /* 4062-4136, 4216-4277, 4378-4842                                           */
 /* ------------------------------------------------------------------------ */
 
-template <bool SHADOW>
-__device__ __forceinline__ int walk_element(const DevScene &sc, const int e, const qr_elem &el, SrfP P,
+template <bool SHADOW, bool DIV, typename SP>
+__device__ __forceinline__ int walk_element(const DevScene &sc, const int e, const qr_elem &el, SP P,
                                             const Ray &r, Walk &w, Hit &h, bool &occluded, bool &live
 #ifdef QR_STATS2
                                              , unsigned long long *g_seg
@@ -765,7 +781,7 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
                     u32 m = ((p == 0 ? cm0 : cm1) && !done) ? 0xFFFFFFFFu : 0u;
                     if (!__any(m != 0) || (SHADOW && QR_KNOB(16))) continue;
                     V3 loc;
-                    m = clip(sc, s, P, r, w, df, dmask, amask, t, side, m, loc
+                    m = clip<DIV>(sc, s, P, r, w, df, dmask, amask, t, side, m, loc
 #ifdef QR_STATS2
                              , g_seg + 4
 #endif
@@ -805,6 +821,11 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
      * enclosing array, which lies at or behind this array's end when arrays are properly nested
      * (sc.nested, verified at upload); otherwise jump only if all rays wait for this array's end.
      */
+    if (DIV)
+    {
+        /* every ray walks alone: one that missed this array's volume goes straight to the array's end */
+        return ((el.kind & 3) == 1 && w.resume == el.data) ? el.data : QR_NULL;
+    }
     if ((el.kind & 3) == 1)
     {
         if (sc.nested ? !__any(live && w.resume == QR_NULL) : !__any(live && w.resume != el.data)) return el.data;
@@ -901,7 +922,7 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
         }
         else
         {
-            jump = walk_element<SHADOW>(sc, e, el, D + el.simd, r, w, h, occluded, live
+            jump = walk_element<SHADOW, false>(sc, e, el, D + el.simd, r, w, h, occluded, live
 #ifdef QR_STATS2
                                  , seg
 #endif
@@ -943,15 +964,82 @@ __device__ __forceinline__ void walk_list(const DevScene &sc, int head, const Ra
 
 
 /*
+ * Divergent walk: every lane walks ITS OWN list at its own pace (element index, cell and surface
+ * record are per-lane vector loads from L2 instead of wave-uniform scalar loads).  For incoherent
+ * rays -- secondary rays of scenes with thousands of small objects, where a wave-packet walk visits
+ * the union of what its rays need and keeps 5 of 64 lanes busy -- this does per-ray work only:
+ * a ray that misses a bounding volume jumps straight behind the array, a ray whose bounding-sphere
+ * test fails steps on alone.  Same per-ray semantics as walk_list (a packet of width one).
+ */
+template <bool SHADOW>
+__device__ __forceinline__ void walk_div(const DevScene &sc, bool active, const Ray &r, Hit &h, bool &occluded)
+{
+    Walk w;
+    w.dxyz = {0, 0, 0}; w.dijk = {0, 0, 0}; w.rijk = {0, 0, 0};
+    w.tbuf = r.tmax;
+    w.local_obj = QR_NULL;
+    w.resume = QR_NULL;
+    bool live = active;
+    int e = active ? r.list : QR_NULL;
+    const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
+    const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    while (__any(e != QR_NULL))
+    {
+        if (e != QR_NULL)
+        {
+            const DCell c = sc.elm[e];
+            qr_elem el; el.simd = c.simd; el.data = c.data; el.next = c.next; el.kind = c.kind;
+            bool skip = false;
+            if (el.kind & 4)
+            {
+                const float ocx = c.cx - r.org.x, ocy = c.cy - r.org.y, ocz = c.cz - r.org.z;
+                const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+                const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+                const float R2 = c.r * c.r;
+                const float q = oc2 - R2;
+                const bool outside = q > 0.01f * R2;
+                const bool miss = (outside && (__builtin_fmaf(oc2 * dd, 1e-5f, b * b) < dd * q || b < 0.0f))
+                               || __builtin_fmaf(-c.r, dlen, b) > w.tbuf * dd;
+                skip = !(live && w.resume == QR_NULL) || (miss && el.simd != r.osi);
+            }
+            int jump = QR_NULL;
+            if (skip)
+            {
+                if (e == w.local_obj) w.local_obj = QR_NULL;
+                if (w.resume == e) w.resume = QR_NULL;
+            }
+            else
+            {
+#ifdef QR_STATS2
+                unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+                jump = walk_element<SHADOW, true>(sc, e, el, sc.srf + el.simd, r, w, h, occluded, live
+#ifdef QR_STATS2
+                                                  , seg_
+#endif
+                                                  );
+            }
+            e = jump != QR_NULL ? jump : el.next;
+            if (SHADOW && !live) e = QR_NULL;
+        }
+    }
+}
+
+/*
  * Wave-wide traversal: lanes with `active` walk their lists; lanes that share
  * a list head are walked together.
  */
-template <bool SHADOW>
+template <bool SHADOW, bool DIV>
 __device__ __forceinline__ void traverse(const DevScene &sc, bool active, const Ray &r, Hit &h, bool &occluded)
 {
     h.t = r.tmax; h.si = QR_NULL; h.side = 0; h.loc = {0, 0, 0};
     occluded = false;
     active = active && r.list != QR_NULL;
+    if (DIV)
+    {
+        walk_div<SHADOW>(sc, active, r, h, occluded);
+        return;
+    }
     unsigned long long pending = __ballot(active);
     while (pending != 0)
     {
@@ -998,7 +1086,7 @@ struct Counters { u32 primary, shadow, reflect, refract; };
 /* state of the enclosing recursion that only has to survive a shade() call */
 struct Outer { V3 ret; int hit_id, sp, mode; };
 
-template <bool COUNT>
+template <bool COUNT, bool DIV>
 __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r, const Hit &h,
                                       Shaded &o, Counters &cnt)
 {
@@ -1157,7 +1245,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
 #ifdef QR_WAVETIME
             const unsigned long long wt_a = __builtin_amdgcn_s_memrealtime();
 #endif
-            traverse<true>(sc, lm, sr, sh, occ);
+            traverse<true, DIV>(sc, lm, sr, sh, occ);
 #ifdef QR_WAVETIME
             if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
                 sc.stats[28 + ((size_t)blockIdx.x * (QR_BLOCK / 64) + (threadIdx.x >> 6)) * QR_WT_SLOTS + 10] += __builtin_amdgcn_s_memrealtime() - wt_a;
@@ -1431,7 +1519,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
 
 __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 
-template <bool COUNT, int WAVES>
+template <bool COUNT, int WAVES, bool DIV = false>
 __global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                       unsigned long long *__restrict__ counters)
@@ -1558,7 +1646,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
 #ifdef QR_X_NOTRACE
             h.t = ray.tmax; h.si = ray.list; h.side = 0; h.loc = ray.ploc; occ = false;
 #else
-            traverse<false>(sc, tr, ray, h, occ);
+            traverse<false, DIV>(sc, tr, ray, h, occ);
 #endif
 #ifdef QR_WAVETIME
             const unsigned long long wt_b = __builtin_amdgcn_s_memrealtime();
@@ -1573,7 +1661,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
             if (got && sp == 0) hit_id = (h.si << 1) | h.side;
 
             Shaded o;
-            shade<COUNT>(sc, got, ray, h, o, cnt);
+            shade<COUNT, DIV>(sc, got, ray, h, o, cnt);
 #ifdef QR_WAVETIME
             if (__ffsll((long long)__ballot(true)) - 1 == lane)
             {

@@ -115,3 +115,24 @@ def test_gpu_scene_without_objects(qr, oracle):
     for rebin in (False, True):
         f = qr.Scene(blob, rebin_tiles=rebin).render(); torch.cuda.synchronize()
         assert (f.cpu().numpy().view(np.uint32) == o_frame).all()
+
+
+@pytest.mark.gpu
+def test_gpu_divergent_walk_variant_matches_oracle(qr, oracle):
+    """QR_DIV=1 forces the per-lane (divergent) list walk, the variant large clipper-free scenes get by
+    themselves (>= 1024 surfaces): same pixels, hit ids and ray counts as the oracle."""
+    import torch
+    blob = _synth().make_scene(**MID)
+    os.environ["QR_DIV"] = "1"
+    try:
+        scn = qr.Scene(blob, rebin_tiles=True)
+    finally:
+        del os.environ["QR_DIV"]
+    frame = scn.new_frame(); ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids); torch.cuda.synchronize()
+    o_frame, o_ids, _ = oracle.render(blob, threads=16, want_ids=True)
+    assert (frame.cpu().numpy().view(np.uint32) == o_frame).all()
+    assert (ids.cpu().numpy() == o_ids).all()
+    _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
+    _, c = scn.render_count()
+    assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}

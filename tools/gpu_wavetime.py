@@ -5,15 +5,19 @@ import os, sys, gzip
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["QR_LIB"] = os.path.join(ROOT, "quadray-engine_amd", "libqrhip_wt.so")
-out = os.path.join(ROOT, "gpurun_out", f"wavetime_{sys.argv[1]}.bin")
+out = os.path.join(ROOT, "gpurun_out", "wavetime_" + sys.argv[1].replace(":", "_") + ".bin")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 os.environ["QR_WAVETIME_OUT"] = out
 sys.path.insert(0, ROOT)
 import torch
 from qr_loader import load_package
 qr = load_package()
-blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", sys.argv[1] + ".qrs.gz"), "rb").read())
-scn = qr.Scene(blob)
+if sys.argv[1].startswith("synth:"):
+    import bench
+    blob = bench.load_blob(sys.argv[1])
+else:
+    blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", sys.argv[1] + ".qrs.gz"), "rb").read())
+scn = qr.Scene(blob, rebin_tiles=sys.argv[1].startswith("synth:"))
 if len(sys.argv) > 2:
     scn.set_depth(int(sys.argv[2]))
 f = scn.new_frame()
