@@ -14,9 +14,9 @@ frames; each frame's 8-row tile rows are dealt to the N ranks in contiguous bloc
 (rotated per frame for balance), every rank renders its blocks of all N frames, then
 ONE exchange over RCCL moves the blocks so that rank f ends the step holding the
 complete frame f.  Per-GPU work is constant in N (weak scaling); the exchange runs on
-its own stream and overlaps the next step's kernels.  Two steps are in flight (--inflight),
+its own stream and overlaps the next step's kernels.  Three steps are in flight (--inflight),
 each launch on its own HIP stream: a frame ends with a few long recursion waves, and the
-next frame's bulk fills the GPU meanwhile (frames are independent, targets double-buffered).
+next frame's bulk fills the GPU meanwhile (frames are independent, one target set per step in flight).
 
 Rays are counted by the backend's counting kernel variant (not timed): primary +
 shadow + reflection + refraction rays actually traced ("useful" rays: the backend
@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="steps (frames per GPU) in flight, each on its own streams")
+    ap.add_argument("--inflight", type=int, default=3, help="steps (frames per GPU) in flight, each on its own streams")
     args = ap.parse_args()
 
     import torch
