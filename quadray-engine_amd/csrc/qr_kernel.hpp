@@ -670,7 +670,16 @@ __device__ __forceinline__ int walk_element(const DevScene &sc, const int e, con
                     const float rk = fxor(vget(ry, mk), sg);
                     dk = fxor(dk, QR_SMASK);
                     cm0 = !same && cne(0.0f, rk);
-                    ct0 = dk / rk;
+                    /* Pre-test (ours): the hit only survives clip() if t_min < t < t_buf.  With t_min >= 0 a
+                     * quotient of opposite signs cannot, and |dk| >= |rk| * t_buf * (1 + 2^-20) means
+                     * t >= t_buf whatever the rounding of the division; dropping those lanes here changes
+                     * nothing, and when no lane is left the wave skips the IEEE division and clip(). */
+                    {
+                        const bool opposite = ((f2u(dk) ^ f2u(rk)) & QR_SMASK) != 0;
+                        const bool beyond = fabs_bits(dk) >= fabs_bits(rk) * (w.tbuf * 1.000001f);
+                        cm0 = cm0 && !((opposite || beyond) && r.tmin >= 0.0f);
+                    }
+                    if (__any(cm0)) ct0 = dk / rk;
                     cs0 = clt(rk, 0.0f) ? 0 : 1;
                     ncand = 1;
                 }
