@@ -212,11 +212,13 @@ struct CellS { qr_elem el; float cx, cy, cz, r; };
 typedef u32 u32x4_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ CellS ld_cell(ElmP p)
 {
-    const QR_CONST u32x4_ *q = (const QR_CONST u32x4_ *)p;
-    const u32x4_ a = q[0], b = q[1];
+    /* one 32-byte load: as two 16-byte halves the compiler sinks the sphere's half behind the test of
+     * `kind`, which makes two dependent scalar-cache round trips per cell */
+    typedef u32 u32x8_ __attribute__((ext_vector_type(8)));
+    const u32x8_ a = *(const QR_CONST u32x8_ *)p;
     CellS c;
-    c.el.simd = (int)a.x; c.el.data = (int)a.y; c.el.next = (int)a.z; c.el.kind = (int)a.w;
-    c.cx = u2f(b.x); c.cy = u2f(b.y); c.cz = u2f(b.z); c.r = u2f(b.w);
+    c.el.simd = (int)a.s0; c.el.data = (int)a.s1; c.el.next = (int)a.s2; c.el.kind = (int)a.s3;
+    c.cx = u2f(a.s4); c.cy = u2f(a.s5); c.cz = u2f(a.s6); c.r = u2f(a.s7);
     return c;
 }
 
