@@ -224,32 +224,34 @@ def main():
     samples_per_frame = rc.primary
 
     ex = sharding.FrameExchange(H, W, N, rank)
-    # --inflight steps are in flight (one render target set each), and the N row blocks of a step are independent
-    # launches: each (buffer, frame) pair has its own HIP stream, so the long recursion waves that end one
-    # launch overlap the bulk of the next instead of idling the GPU (DESIGN.md "Critical path").
+    # --inflight steps are in flight (one render target set and one HIP stream each), so the long recursion
+    # waves that end one launch overlap the bulk of the next instead of idling the GPU (DESIGN.md "Critical path").
     D = max(1, args.inflight)
-    streams = [[torch.cuda.Stream() for _ in range(N)] for _ in range(D)]
-    compute = streams[0][0]
+    streams = [torch.cuda.Stream() for _ in range(D)]
+    compute = streams[0]
     comm = torch.cuda.Stream()
     frames = [[scn.new_frame() for _ in range(N)] for _ in range(D)]    # render targets of the steps in flight
     finals = [scn.new_frame() for _ in range(D)]                        # the frame this rank assembles
-    ev_render = [[torch.cuda.Event() for _ in range(N)] for _ in range(D)]
+    ev_render = [torch.cuda.Event() for _ in range(D)]
     ev_comm = [torch.cuda.Event() for _ in range(D)]
+    # the N blocks this rank owns in a step (block (rank + f) mod N of frame f) go out as ONE multi-target
+    # launch (qr_render_multi_async): cut into N launches the same work costs 2-2.6x (ramp, drain and tail of
+    # every small grid; measured on one GPU, tools/gpu_shard_overhead.py)
+    multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(D)] if N > 1 else None
 
     def step(i):
         buf = i % D
-        for f in range(N):
-            st = streams[buf][f]
-            with torch.cuda.stream(st):
-                st.wait_event(ev_comm[buf])                 # the exchange that last read this buffer is done
-                r0, r1 = ex.my_rows(f)
-                scn.set_rows(r0, r1, 0, 1)
-                scn.render(frames[buf][f], stream=st)
-                ev_render[buf][f].record(st)
+        st = streams[buf]
+        with torch.cuda.stream(st):
+            st.wait_event(ev_comm[buf])                     # the exchange that last read this buffer is done
+            if N > 1:
+                multi[buf](stream=st)
+            else:
+                scn.render(frames[buf][0], stream=st)
+            ev_render[buf].record(st)
         if N > 1:
             with torch.cuda.stream(comm):
-                for f in range(N):
-                    comm.wait_event(ev_render[buf][f])
+                comm.wait_event(ev_render[buf])
                 ex.exchange(frames[buf], finals[buf])
                 ev_comm[buf].record(comm)
 

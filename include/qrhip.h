@@ -145,6 +145,16 @@ int qr_scene_set_tile_rows(qr_device_scene *scn, int first, int stride);
 int qr_render_async(qr_device_scene *scn, void *frame_dev, void *stream);
 
 /*
+ * One launch for several row ranges: target i renders rows [row_begin[i], row_end[i]) of scenes[i] into
+ * frames_dev[i] (device memory, compact stride as for qr_render_async).  The scenes may be the same or
+ * different ones on the same device; at most 16 targets.  This is what a GPU does in a sharded step (its
+ * block of every frame in flight, see quadray-engine_amd/sharding.py): issued as separate launches the
+ * blocks pay a ramp, a drain and a tail each.  Asynchronous on `stream`.
+ */
+int qr_render_multi_async(int n, qr_device_scene *const *scenes, void *const *frames_dev,
+                          const int *row_begin, const int *row_end, void *stream);
+
+/*
  * As qr_render_async, additionally writing the visible primary hit of every
  * pixel to `ids_dev` (int32 per pixel: surface_index << 1 | side, -1 = none).
  * The reference has no such buffer; it is compared against the oracle's.

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR
 ABI_SYMBOLS = [
     "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
     "qr_scene_upload", "qr_scene_upload_ex", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
-    "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_ids_async",
+    "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
     "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
 ]
@@ -83,6 +83,7 @@ def lib():
     L.qr_scene_set_tile_rows.argtypes = [vp, ci, ci]
     L.qr_render_async.argtypes = [vp, vp, vp]
     L.qr_render_ids_async.argtypes = [vp, vp, vp, vp]
+    L.qr_render_multi_async.argtypes = [ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(ci), vp]
     L.qr_render_count.argtypes = [vp, vp, vp, ctypes.POINTER(RayCounts)]
     L.qr_render_host.argtypes = [vp, vp, ci]
     L.qr_render_timed.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
@@ -185,3 +186,20 @@ class Scene:
         out = np.zeros((self.height, self.width), dtype=np.uint32)
         _check(lib().qr_render_host(self._h, out.ctypes.data_as(ctypes.c_void_p), self.width))
         return out
+
+
+class MultiRender:
+    """Prepared multi-target launch (qr_render_multi_async): targets = [(scene, frame tensor, row_begin, row_end)].
+    The ctypes argument arrays are built once; call it with a stream to launch."""
+
+    def __init__(self, targets):
+        n = len(targets)
+        self.n = n
+        self._keep = targets
+        self._scenes = (ctypes.c_void_p * n)(*[t[0]._h.value for t in targets])
+        self._frames = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in targets])
+        self._r0 = (ctypes.c_int * n)(*[int(t[2]) for t in targets])
+        self._r1 = (ctypes.c_int * n)(*[int(t[3]) for t in targets])
+
+    def __call__(self, stream=None):
+        _check(lib().qr_render_multi_async(self.n, self._scenes, self._frames, self._r0, self._r1, Scene._stream_ptr(stream)))

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <mutex>
 #include <map>
 #include <array>
 #include <algorithm>
@@ -46,6 +47,8 @@ struct qr_device_scene
     struct SubSched { uint32_t *d_order; int32_t n; };
     std::map<std::array<int32_t, 6>, SubSched> sub;
 };
+
+static void multi_forget(const qr_device_scene *s);
 
 extern "C" const char *qr_kernel_name(void) { return "qr_render_kernel"; }
 
@@ -914,6 +917,7 @@ extern "C" int qr_scene_destroy(qr_device_scene *s)
 {
     if (s == nullptr) return QR_OK;
     (void)hipSetDevice(s->device);
+    multi_forget(s);
     (void)hipEventDestroy(s->ev0);
     (void)hipEventDestroy(s->ev1);
     for (auto &kv : s->sub) (void)hipFree(kv.second.d_order);
@@ -1039,6 +1043,116 @@ extern "C" int qr_render_async(qr_device_scene *s, void *frame_dev, void *stream
     if (s == nullptr || frame_dev == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch<false>(s, frame_dev, nullptr, (hipStream_t)stream));
+    return QR_OK;
+}
+
+/* combined schedules of multi-target launches, keyed by (scene, row range) per target */
+struct MultiSched { uint32_t *d_order; DevScene *d_scenes; int32_t n; };
+static std::map<std::vector<int64_t>, MultiSched> g_multi;
+static std::mutex g_multi_lock;
+
+static void multi_forget(const qr_device_scene *s)
+{
+    std::lock_guard<std::mutex> lk(g_multi_lock);
+    for (auto it = g_multi.begin(); it != g_multi.end(); )
+    {
+        bool uses = false;
+        for (size_t i = 0; i < it->first.size(); i += 3) if (it->first[i] == (int64_t)(intptr_t)s) uses = true;
+        if (uses) { (void)hipFree(it->second.d_order); (void)hipFree(it->second.d_scenes); it = g_multi.erase(it); }
+        else ++it;
+    }
+}
+
+extern "C" int qr_render_multi_async(int n, qr_device_scene *const *scenes, void *const *frames_dev,
+                                     const int *row_begin, const int *row_end, void *stream)
+{
+    if (n <= 0 || scenes == nullptr || frames_dev == nullptr || row_begin == nullptr || row_end == nullptr)
+        return qr_fail(QR_ERR_ARG, "bad argument");
+    bool direct = n <= QR_MAX_TARGETS;
+    for (int i = 0; i < n; i++)
+    {
+        if (scenes[i] == nullptr || frames_dev[i] == nullptr) return qr_fail(QR_ERR_ARG, "null scene or frame");
+        if (scenes[i]->device != scenes[0]->device) return qr_fail(QR_ERR_ARG, "scenes live on different devices");
+        if (row_begin[i] < 0 || row_end[i] > scenes[i]->fr.frm_h || row_begin[i] > row_end[i]) return qr_fail(QR_ERR_ARG, "bad row range");
+        if (scenes[i]->divergent) direct = false;
+    }
+#ifdef QR_WAVETIME
+    direct = false;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(scenes[0]->device));
+    if (!direct)
+    {
+        /* no combined kernel for this set: one launch per target */
+        for (int i = 0; i < n; i++)
+        {
+            qr_device_scene *s = scenes[i];
+            const DevScene keep = s->sc;
+            int rc = qr_scene_set_rows(s, row_begin[i], row_end[i], 0, 1);
+            if (rc == QR_OK) { hipError_t e = launch<false>(s, frames_dev[i], nullptr, st); if (e != hipSuccess) rc = qr_fail(QR_ERR_DEVICE, hipGetErrorString(e)); }
+            s->sc = keep;
+            if (rc != QR_OK) return rc;
+        }
+        return QR_OK;
+    }
+    std::vector<int64_t> key;
+    for (int i = 0; i < n; i++) { key.push_back((int64_t)(intptr_t)scenes[i]); key.push_back(row_begin[i]); key.push_back(row_end[i]); }
+    MultiSched ms;
+    {
+        std::lock_guard<std::mutex> lk(g_multi_lock);
+        auto it = g_multi.find(key);
+        if (it == g_multi.end())
+        {
+            std::vector<uint32_t> ent[4];                    /* by heaviness (schedule word bits 30-31) */
+            std::vector<DevScene> dsc((size_t)n);
+            for (int i = 0; i < n; i++)
+            {
+                const qr_device_scene *s = scenes[i];
+                dsc[i] = s->sc;
+                dsc[i].row_begin = 0; dsc[i].row_end = s->fr.frm_h; dsc[i].index = 0; dsc[i].thnum = 1;
+                dsc[i].group_first = 0; dsc[i].group_stride = 1;
+                const int fh = s->fr.fsaa == 0 ? 8 : 4;
+                for (size_t k = 0; k + 1 < s->h_order.size(); k += 2)
+                {
+                    const int y0 = (int)((s->h_order[k] >> 14) & 0x3FFFu) * fh;
+                    if (y0 + fh <= row_begin[i] || y0 >= row_end[i]) continue;
+                    std::vector<uint32_t> &v = ent[3 - (s->h_order[k] >> 30)];
+                    v.push_back(s->h_order[k]); v.push_back(s->h_order[k + 1]); v.push_back((uint32_t)i); v.push_back(0u);
+                }
+            }
+            std::vector<uint32_t> all;
+            for (int h = 0; h < 4; h++) all.insert(all.end(), ent[h].begin(), ent[h].end());
+            if (g_multi.size() >= 64)
+            {
+                (void)hipDeviceSynchronize();
+                for (auto &kv : g_multi) { (void)hipFree(kv.second.d_order); (void)hipFree(kv.second.d_scenes); }
+                g_multi.clear();
+            }
+            MultiSched m = { nullptr, nullptr, (int32_t)(all.size() / 4) };
+            HIP_TRY(hipMalloc((void **)&m.d_scenes, dsc.size() * sizeof(DevScene)));
+            HIP_TRY(hipMemcpy(m.d_scenes, dsc.data(), dsc.size() * sizeof(DevScene), hipMemcpyHostToDevice));
+            if (m.n > 0)
+            {
+                HIP_TRY(hipMalloc((void **)&m.d_order, all.size() * 4));
+                HIP_TRY(hipMemcpy(m.d_order, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+            }
+            it = g_multi.emplace(key, m).first;
+        }
+        ms = it->second;
+    }
+    if (ms.n == 0) return QR_OK;
+    DevTargets tg;
+    memset(&tg, 0, sizeof(tg));
+    for (int i = 0; i < n; i++)
+    {
+        tg.t[i].frame = (uint32_t *)frames_dev[i];
+        tg.t[i].row_begin = row_begin[i]; tg.t[i].row_end = row_end[i];
+        tg.t[i].scene = i;
+    }
+    const dim3 grid((unsigned)((ms.n + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64)), 1, 1);
+    hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD>), grid, dim3(QR_BLOCK), 0, st,
+                       (const DevScene *)ms.d_scenes, tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
+    HIP_TRY(hipGetLastError());
     return QR_OK;
 }
 

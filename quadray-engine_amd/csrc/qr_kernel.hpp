@@ -1530,10 +1530,11 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
 
 __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 
-template <bool COUNT, int WAVES, bool DIV = false>
-__global__ __launch_bounds__(QR_BLOCK, WAVES)
-void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
-                      unsigned long long *__restrict__ counters)
+/* one wave = one schedule entry: footprint `ord`, its tile-list head, rendered into `frame` */
+template <bool COUNT, bool DIV>
+__device__ __forceinline__ void render_wave(const DevScene &sc, const u32 ord, const int sched_head, const int gw,
+                                            uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
+                                            unsigned long long *__restrict__ counters)
 {
 #ifdef QR_WAVETIME
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
@@ -1553,13 +1554,7 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
      * long waves overlap the bulk instead of forming a tail); consecutive entries are
      * neighbouring footprints, so the waves of a workgroup still share tile lists. */
     const int fw = fsaa == 2 ? 4 : 8, fh = fsaa == 0 ? 8 : 4;
-    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (QR_BLOCK / 64) + wv);
-    if (gw >= sc.n_blocks) return;
-    /* schedule entry {footprint coordinates, tile-list head or QR_PER_LANE_TILE}: one scalar load */
-    typedef u32 u32x2_ __attribute__((ext_vector_type(2)));
-    const u32x2_ sched = ((const QR_CONST u32x2_ *)sc.order)[gw];
-    const u32 ord = sched.x;
-    const int sched_head = (int)sched.y;
+    (void)wv; (void)gw;
     /* footprints that can recurse get issue priority: the frame ends with the slowest of them, and while
      * the bulk is in flight they would otherwise share their SIMD's issue slots evenly */
     if (ord >> 30) { if ((ord >> 30) >= 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
@@ -1841,6 +1836,56 @@ void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__rest
             if (lane == 0 && s != 0) atomicAdd(&counters[i], s);
         }
     }
+}
+
+/* single-scene launch: the scene record travels in the kernel arguments */
+template <bool COUNT, int WAVES, bool DIV = false>
+__global__ __launch_bounds__(QR_BLOCK, WAVES)
+void qr_render_kernel(DevScene sc, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
+                      unsigned long long *__restrict__ counters)
+{
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (QR_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (gw >= sc.n_blocks) return;
+    /* schedule entry {footprint coordinates, tile-list head or QR_PER_LANE_TILE}: one scalar load */
+    typedef u32 u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ sched = ((const QR_CONST u32x2_ *)sc.order)[gw];
+    render_wave<COUNT, DIV>(sc, sched.x, (int)sched.y, gw, frame, ids, counters);
+}
+
+/*
+ * Multi-target launch (qr_render_multi_async): ONE grid renders row ranges of several frames -- of the
+ * same or of different scenes -- so that the N blocks a GPU owns in a sharded step share one launch: a
+ * frame cut into N small launches pays N ramps, drains and tails (0.23 ms for 8 blocks of demo1 at
+ * 1080p against 0.09 ms for the whole frame).  Schedule entries are 16 bytes {footprint, tile-list
+ * head, target index, 0}, heavy footprints of all targets first.
+ */
+#define QR_MAX_TARGETS 16
+struct DevTarget { uint32_t *frame; int32_t row_begin, row_end; int32_t scene, pad; };
+struct DevTargets { DevTarget t[QR_MAX_TARGETS]; };
+
+template <int WAVES>
+__global__ __launch_bounds__(QR_BLOCK, WAVES)
+void qr_render_multi_kernel(const DevScene *__restrict__ scenes, DevTargets tg,
+                            const uint32_t *__restrict__ order16, int n_blocks,
+                            unsigned long long *__restrict__ counters)
+{
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (QR_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (gw >= n_blocks) return;
+    const u32x4 sched = ((const QR_CONST u32x4 *)order16)[gw];
+    const int ti = (int)sched.z;
+    const DevTarget t = tg.t[ti];
+    DevScene sc;
+    {
+        /* dword-wise copy from the constant address space (scalar loads) */
+        const QR_CONST u32 *src = (const QR_CONST u32 *)(scenes + t.scene);
+        u32 *dst = (u32 *)&sc;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(DevScene) / 4; i++) dst[i] = src[i];
+    }
+    sc.row_begin = t.row_begin; sc.row_end = t.row_end;
+    sc.index = 0; sc.thnum = 1;
+    sc.group_first = t.row_begin / 8; sc.group_stride = 1;
+    render_wave<false, false>(sc, sched.x, (int)sched.y, gw, t.frame, nullptr, counters);
 }
 
 #endif /* QR_KERNEL_HPP */

@@ -143,3 +143,25 @@ def _hash(frame):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import qr_oracle
     return qr_oracle.frame_hash(frame)
+
+
+def test_gpu_multi_target_launch_matches_separate_launches(qr):
+    """qr_render_multi_async: row blocks of the same scene and of two different scenes (different sizes,
+    FSAA, options) rendered by ONE launch equal what separate launches give."""
+    import torch
+    a = qr.Scene(load_blob("demo01_160"))
+    b = qr.Scene(load_blob("demo02_160_gf_aa4"))
+    whole_a = a.render(); whole_b = b.render(); torch.cuda.synchronize()
+    fa = [torch.full_like(whole_a, 0x55) for _ in range(3)]
+    fb = torch.full_like(whole_b, 0x55)
+    ha, hb = a.height, b.height
+    cuts = [0, 40, 48, ha]
+    targets = [(a, fa[i], cuts[i], cuts[i + 1]) for i in range(3)] + [(b, fb, 17, hb - 9)]
+    qr.MultiRender(targets)()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert bool((fa[i][cuts[i]:cuts[i + 1]] == whole_a[cuts[i]:cuts[i + 1]]).all())
+        outside = torch.cat([fa[i][:cuts[i]], fa[i][cuts[i + 1]:]])
+        assert bool((outside == 0x55).all()), "rows outside the range must stay untouched"
+    assert bool((fb[17:hb - 9] == whole_b[17:hb - 9]).all())
+    assert bool((fb[:17] == 0x55).all()) and bool((fb[hb - 9:] == 0x55).all())
