@@ -227,36 +227,49 @@ def main():
     # --inflight steps are in flight (one render target set and one HIP stream each), so the long recursion
     # waves that end one launch overlap the bulk of the next instead of idling the GPU (DESIGN.md "Critical path").
     D = max(1, args.inflight)
+    B = 2 * D if N > 1 else D                                           # two groups of D steps: one renders while the other is exchanged
     streams = [torch.cuda.Stream() for _ in range(D)]
     compute = streams[0]
     comm = torch.cuda.Stream()
-    frames = [[scn.new_frame() for _ in range(N)] for _ in range(D)]    # render targets of the steps in flight
-    finals = [scn.new_frame() for _ in range(D)]                        # the frame this rank assembles
-    ev_render = [torch.cuda.Event() for _ in range(D)]
-    ev_comm = [torch.cuda.Event() for _ in range(D)]
+    frames = [[scn.new_frame() for _ in range(N)] for _ in range(B)]    # render targets of the steps in flight
+    finals = [scn.new_frame() for _ in range(B)]                        # the frame this rank assembles
+    ev_render = [torch.cuda.Event() for _ in range(B)]
+    ev_comm = [torch.cuda.Event() for _ in range(2)]                    # per group of D steps
     # the N blocks this rank owns in a step (block (rank + f) mod N of frame f) go out as ONE multi-target
     # launch (qr_render_multi_async): cut into N launches the same work costs 2-2.6x (ramp, drain and tail of
     # every small grid; measured on one GPU, tools/gpu_shard_overhead.py)
-    multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(D)] if N > 1 else None
+    multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(B)] if N > 1 else None
+    state = {"pending": []}
+
+    def flush():
+        """one grouped exchange for the steps rendered since the last one (fewer, larger collectives)"""
+        if N > 1 and state["pending"]:
+            grp = state["pending"][0] // D
+            with torch.cuda.stream(comm):
+                for b in state["pending"]:
+                    comm.wait_event(ev_render[b])
+                ex.exchange_many([(frames[b], finals[b]) for b in state["pending"]])
+                ev_comm[grp].record(comm)
+            state["pending"] = []
 
     def step(i):
-        buf = i % D
-        st = streams[buf]
+        buf = i % B
+        st = streams[i % D]
         with torch.cuda.stream(st):
-            st.wait_event(ev_comm[buf])                     # the exchange that last read this buffer is done
             if N > 1:
+                st.wait_event(ev_comm[buf // D])            # the exchange that last read this group of buffers is done
                 multi[buf](stream=st)
             else:
                 scn.render(frames[buf][0], stream=st)
             ev_render[buf].record(st)
         if N > 1:
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev_render[buf])
-                ex.exchange(frames[buf], finals[buf])
-                ev_comm[buf].record(comm)
+            state["pending"].append(buf)
+            if len(state["pending"]) == D:
+                flush()
 
     for i in range(args.warmup):
         step(i)
+    flush()
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
@@ -264,6 +277,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    flush()
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
@@ -281,7 +295,7 @@ def main():
         scn.set_rows(0, H, 0, 1)
         scn.render(whole)
         torch.cuda.synchronize()
-        ok = bool((whole == finals[(args.steps - 1) % D]).all().item())
+        ok = bool((whole == finals[(args.steps - 1) % B]).all().item())
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -325,7 +339,7 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
                        "frames_per_step": N, "steps_in_flight": D, "rays_per_frame": rays_per_frame,
                        "rays": rc.as_dict(),
-                       "parallelism": f"tile-row blocks x{N} + 1 exchange/step" if N > 1 else "single GPU",
+                       "parallelism": f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
                        "assembled_frame_matches": ok},
             "roofline": roofline,

@@ -48,36 +48,43 @@ class FrameExchange:
         """frames: list of `world` [h,w] tensors (rank's blocks rendered in place);
         final: [h,w] tensor receiving frame `rank`.  Returns after the transfers completed
         (on the current stream for NCCL)."""
+        self.exchange_many([(frames, final)], group)
+
+    def exchange_many(self, steps, group=None):
+        """The exchanges of several steps as ONE grouped call: `steps` = [(frames, final), ...] in the same
+        order on every rank.  Fewer, larger collectives: a grouped send/recv has a fixed cost of tens of
+        microseconds on RCCL, comparable to a whole step of demo-scene rendering."""
         world, rank, lo = self.world, self.rank, self.lo
         if world == 1:
-            final.copy_(frames[0])
+            for frames, final in steps:
+                final.copy_(frames[0])
             return
         # gloo has no device-memory send/recv: stage through host memory (CPU tests, one-GPU rehearsals)
-        staged = final.is_cuda and dist.get_backend(group) == "gloo"
+        staged = steps[0][1].is_cuda and dist.get_backend(group) == "gloo"
         if staged:
             torch.cuda.current_stream().synchronize()
-            recv_host = {}
+        recv_host = []
         ops, keep = [], []
-        for peer in range(world):
-            sb = block_of(rank, peer, world)            # my block of frame `peer` goes to rank `peer`
-            rb = block_of(peer, rank, world)            # peer's block of frame `rank` comes to me
-            src = frames[peer][lo[sb]:lo[sb + 1]]
-            dst = final[lo[rb]:lo[rb + 1]]
-            if peer == rank:
-                dst.copy_(src)
-                continue
-            if staged:
-                src = src.cpu()
-                recv_host[peer] = (torch.empty(dst.shape, dtype=dst.dtype), dst)
-                dst = recv_host[peer][0]
-            if src.numel():
-                ops.append(dist.P2POp(dist.isend, src, peer, group))
-            if dst.numel():
-                ops.append(dist.P2POp(dist.irecv, dst, peer, group))
-            keep += [src, dst]
+        for frames, final in steps:
+            for peer in range(world):
+                sb = block_of(rank, peer, world)            # my block of frame `peer` goes to rank `peer`
+                rb = block_of(peer, rank, world)            # peer's block of frame `rank` comes to me
+                src = frames[peer][lo[sb]:lo[sb + 1]]
+                dst = final[lo[rb]:lo[rb + 1]]
+                if peer == rank:
+                    dst.copy_(src)
+                    continue
+                if staged:
+                    src = src.cpu()
+                    recv_host.append((torch.empty(dst.shape, dtype=dst.dtype), dst))
+                    dst = recv_host[-1][0]
+                if src.numel():
+                    ops.append(dist.P2POp(dist.isend, src, peer, group))
+                if dst.numel():
+                    ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+                keep += [src, dst]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        if staged:
-            for host, dev in recv_host.values():
-                dev.copy_(host)
+        for host, dev in recv_host:
+            dev.copy_(host)
