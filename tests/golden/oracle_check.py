@@ -5,7 +5,7 @@ Usage: oracle_check.py SCENE W H [--fsaa N] [--gamma] [--fresnel] [--depth D] [-
 import ctypes, subprocess, sys, os, tempfile
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 def load_oracle():
