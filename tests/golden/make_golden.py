@@ -42,6 +42,20 @@ case("demo01_160_d0", "demo01", 160, 120, ["--depth", "0"])
 case("demo02_160_gf_d3", "demo02", 160, 120, ["--gamma", "--fresnel", "--depth", "3"])
 case("demo01_odd_157x93", "demo01", 157, 93)            # ragged: width not a multiple of any tile / SIMD width
 case("demo02_odd_33x17_aa4", "demo02", 33, 17, ["--fsaa", "4", "--gamma"])
+# other cameras of the scenes (rt_Scene::next_cam), other animation times, recursion depths, option mixes
+for d in ("demo01", "demo02", "demo03"):
+    if d != "demo01":                                   # demo01 has a single camera
+        case(f"{d}_160_cam1", d, 160, 120, ["--camera", "1"])
+    case(f"{d}_160_cam2_gf_aa2", d, 160, 120, ["--camera", "2", "--gamma", "--fresnel", "--fsaa", "2"])
+case("demo01_160_t12345", "demo01", 160, 120, ["-t", "12345"])
+case("demo02_160_t7777_gf", "demo02", 160, 120, ["-t", "7777", "--gamma", "--fresnel"])
+case("demo03_160_t9999_aa4", "demo03", 160, 120, ["-t", "9999", "--fsaa", "4"])
+case("demo02_160_d1", "demo02", 160, 120, ["--depth", "1"])
+case("demo02_160_gf_d5", "demo02", 160, 120, ["--gamma", "--fresnel", "--depth", "5"])
+case("test07_160_gf", "test07", 160, 120, ["--gamma", "--fresnel"])
+case("test13_160_gf_aa4", "test13", 160, 120, ["--gamma", "--fresnel", "--fsaa", "4"])
+case("test18_160_gf_t4000", "test18", 160, 120, ["--gamma", "--fresnel", "-t", "4000"])
+case("demo03_320x240_aa4_gf", "demo03", 320, 240, ["--fsaa", "4", "--gamma", "--fresnel"])
 # BASELINE.json configs
 case("c1_demo01_640x480", "demo01", 640, 480)
 case("c2_demo01_1080p_d0", "demo01", 1920, 1080, ["--depth", "0"], keep_frame=False)
