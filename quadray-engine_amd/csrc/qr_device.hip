@@ -59,7 +59,17 @@ extern "C" int qr_device_count(void)
     return n;
 }
 
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static size_t pad16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+/* Tried and dropped for the drop-in path: page-locking the engine's frame in place for a direct DMA
+ * copy-back saves 0.35 ms per 1080p frame on demo1 but makes demo2 ten times slower (host accesses to the
+ * engine's heap next to the frame and later copies slow down once the range is registered); recycling the
+ * scene's device allocation between calls showed the same effect. */
 
 /*
  * Conservative WORLD-space bounding sphere of the visible part of surface `i`, derived from
@@ -824,7 +834,25 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     size_t o_bs = pad16(o_frm + sizeof(qr_frame));
     size_t total = pad16(o_bs + bsph.size() * sizeof(BSphere));
 
-    std::vector<uint8_t> host(total, 0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    /* staging buffer in page-locked memory, kept per thread: a pageable host-to-device copy above ~1 MB
+     * takes 13-23 ms on this stack (the runtime pins the source on the fly), a pinned one 0.1 ms */
+    static thread_local struct Staging { uint8_t *p = nullptr; size_t cap = 0; } stage;
+    if (stage.cap < total)
+    {
+        if (stage.p) (void)hipHostFree(stage.p);
+        stage.p = nullptr; stage.cap = 0;
+        const size_t cap = total + total / 2;
+        HIP_TRY(hipHostMalloc((void **)&stage.p, cap, hipHostMallocDefault));
+        stage.cap = cap;
+    }
+    struct HostView { uint8_t *p; uint8_t *data() const { return p; } } host = { stage.p };
+    memset(host.p, 0, total);
     memcpy(host.data() + o_srf, dsurf.data(), dsurf.size() * sizeof(DSurf));
     memcpy(host.data() + o_shd, dshade.data(), dshade.size() * sizeof(DShade));
     memcpy(host.data() + o_mat, v.mat, (size_t)n_mat * sizeof(qr_material));
@@ -850,18 +878,15 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     memcpy(host.data() + o_frm, &frm, sizeof(qr_frame));
     memcpy(host.data() + o_bs, bsph.data(), bsph.size() * sizeof(BSphere));
 
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return qr_fail(QR_ERR_DEVICE, "no HIP device available (the gfx950 backend has no CPU fallback)");
-    if (device < 0 || device >= ndev) return qr_fail(QR_ERR_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
-
     qr_device_scene *s = new qr_device_scene();     /* value-initialised: plain members are zero */
     s->device = device;
     s->hdr = *v.hdr;
+    const double tm0 = now_ms();
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    const double tm1 = now_ms();
     e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (getenv("QR_VERBOSE")) fprintf(stderr, "upload: device bytes %zu, hipMalloc %.3f ms, hipMemcpy %.3f ms\n", total, tm1 - tm0, now_ms() - tm1);
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
 #ifdef QR_WAVETIME
     e = hipMalloc((void **)&s->d_counters, (32 + QR_WT_SLOTS * n_sched) * sizeof(unsigned long long));
@@ -869,8 +894,6 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     e = hipMalloc((void **)&s->d_counters, 32 * sizeof(unsigned long long));
 #endif
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-    (void)hipEventCreate(&s->ev0);
-    (void)hipEventCreate(&s->ev1);
     s->blob_bytes = total;
 
     uint8_t *d = (uint8_t *)s->d_blob;
@@ -918,8 +941,8 @@ extern "C" int qr_scene_destroy(qr_device_scene *s)
     if (s == nullptr) return QR_OK;
     (void)hipSetDevice(s->device);
     multi_forget(s);
-    (void)hipEventDestroy(s->ev0);
-    (void)hipEventDestroy(s->ev1);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (auto &kv : s->sub) (void)hipFree(kv.second.d_order);
     (void)hipFree(s->d_counters);
     (void)hipFree(s->d_blob);
@@ -1208,6 +1231,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
     double sum = 0.0; float mn = 1e30f;
+    if (s->ev0 == nullptr) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     for (int i = 0; i < iters; i++)
     {
 #ifdef QR_WAVETIME
@@ -1271,12 +1295,12 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
         HIP_TRY(hipHostMalloc((void **)&c.h_frame, bytes, hipHostMallocDefault));
         c.h_cap = bytes;
     }
+    const bool whole = s->sc.row_begin == 0 && s->sc.row_end == h && s->sc.group_first == 0 && s->sc.group_stride == 1 && s->sc.thnum <= 1;
     hipError_t e = launch<false>(s, c.d_frame, nullptr, nullptr);
     if (e == hipSuccess) e = hipMemcpy(c.h_frame, c.d_frame, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     /* copy only the rows this call owns, honouring a negative stride (bottom-up
      * frames, engine.cpp:2814-2850) */
-    const bool whole = s->sc.row_begin == 0 && s->sc.row_end == h && s->sc.group_first == 0 && s->sc.group_stride == 1 && s->sc.thnum <= 1;
     if (whole && row_pixels == w)
     {
         memcpy(frame_host, c.h_frame, bytes);
@@ -1297,11 +1321,6 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
  * and animates objects every frame (engine.cpp:2976-3332); all of that is a few
  * hundred KB.
  */
-static double now_ms()
-{
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
 extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
 {
     const bool verbose = getenv("QR_VERBOSE") != nullptr;
