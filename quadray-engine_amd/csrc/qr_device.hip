@@ -452,16 +452,65 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
                 (void)bound_sphere(v, el.simd, &bx);
                 if (bx.valid && vx && vy)
                 {
-                    double bxl = 1e300, bxh = -1e300, byl = 1e300, byh = -1e300; bool front = true;
-                    for (int c = 0; c < 8 && front; c++)
+                    /* camera-space corners; the part of the box in front of the plane z = zn is the convex hull
+                     * of the corners in front and of the points where box edges cross that plane, so the
+                     * rectangle of their projections bounds everything a primary ray can meet */
+                    double cam[8][3];
+                    for (int c = 0; c < 8; c++)
                     {
                         double pa = 0.0, pb = 0.0, pz = 0.0;
                         for (int k = 0; k < 3; k++) { const double qk = bx.p[c][k] - frm.org[k]; pa += qk * u[k]; pb += qk * w2[k]; pz += qk * ww[k]; }
-                        if (!(pz > 1e-3 * pov)) { front = false; break; }
-                        const double sx = cx + (pa / pz) * (pov / hl), sy = cy + (pb / pz) * (pov / vl);
-                        if (sx < bxl) bxl = sx; if (sx > bxh) bxh = sx; if (sy < byl) byl = sy; if (sy > byh) byh = sy;
+                        cam[c][0] = pa; cam[c][1] = pb; cam[c][2] = pz;
                     }
-                    if (front)
+                    const double zn = 1e-3 * pov;
+                    double bxl = 1e300, bxh = -1e300, byl = 1e300, byh = -1e300; int npts = 0;
+                    /* Each face of the box is clipped (Sutherland-Hodgman) against the eye plane and the four
+                     * sides of the view pyramid widened by 4 pixels, and what is left is projected: a wall that
+                     * runs past the eye then covers the part of the screen it fills, not all of it. */
+                    const double kx0 = (-4.0 - cx) * hl / pov, kx1 = (frm.frm_w + 4.0 - cx) * hl / pov;
+                    const double ky0 = (-4.0 - cy) * vl / pov, ky1 = (frm.frm_h + 4.0 - cy) * vl / pov;
+                    static const int face[6][4] = { {0, 1, 3, 2}, {4, 5, 7, 6}, {0, 1, 5, 4}, {2, 3, 7, 6}, {0, 2, 6, 4}, {1, 3, 7, 5} };
+                    for (int f = 0; f < 6; f++)
+                    {
+                        double poly[16][3], tmp[16][3]; int np = 4;
+                        for (int i = 0; i < 4; i++) for (int k = 0; k < 3; k++) poly[i][k] = cam[face[f][i]][k];
+                        for (int pl = 0; pl < 5 && np > 0; pl++)
+                        {
+                            auto dist = [&](const double *q) {
+                                switch (pl) {
+                                case 0: return q[2] - zn;
+                                case 1: return q[0] - kx0 * q[2];
+                                case 2: return kx1 * q[2] - q[0];
+                                case 3: return q[1] - ky0 * q[2];
+                                default: return ky1 * q[2] - q[1];
+                                }
+                            };
+                            int nt = 0;
+                            for (int i = 0; i < np; i++)
+                            {
+                                const double *p0 = poly[i], *p1 = poly[(i + 1) % np];
+                                const double d0 = dist(p0), d1 = dist(p1);
+                                if (d0 >= 0.0) { for (int k = 0; k < 3; k++) tmp[nt][k] = p0[k]; nt++; }
+                                if ((d0 >= 0.0) != (d1 >= 0.0))
+                                {
+                                    const double t = d0 / (d0 - d1);
+                                    for (int k = 0; k < 3; k++) tmp[nt][k] = p0[k] + t * (p1[k] - p0[k]);
+                                    nt++;
+                                }
+                            }
+                            np = nt < 16 ? nt : 16;
+                            for (int i = 0; i < np; i++) for (int k = 0; k < 3; k++) poly[i][k] = tmp[i][k];
+                        }
+                        for (int i = 0; i < np; i++)
+                        {
+                            const double pz = poly[i][2] > zn ? poly[i][2] : zn;
+                            const double sx = cx + (poly[i][0] / pz) * (pov / hl), sy = cy + (poly[i][1] / pz) * (pov / vl);
+                            if (sx < bxl) bxl = sx; if (sx > bxh) bxh = sx; if (sy < byl) byl = sy; if (sy > byh) byh = sy;
+                            npts++;
+                        }
+                    }
+                    if (npts == 0) { xl = 1e300; xh = -1e300; }           /* the whole box is behind the eye */
+                    else
                     {
                         /* a margin relative to the box size covers the 1e-3 inflation of the bounds */
                         const double ex = 2e-3 * (bxh - bxl) + 1e-3, ey = 2e-3 * (byh - byl) + 1e-3;
@@ -470,7 +519,7 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
                     }
                 }
                 const double mg = 2.0;                              /* FSAA sample offsets (< 0.5 px) + fp32 ray rounding */
-                if (!vx || !vy || xh + mg < 0.0 || yh + mg < 0.0 || xl - mg > frm.frm_w || yl - mg > frm.frm_h) { b.x0 = 1; b.x1 = 0; }
+                if (!vx || !vy || xl > xh || yl > yh || xh + mg < 0.0 || yh + mg < 0.0 || xl - mg > frm.frm_w || yl - mg > frm.frm_h) { b.x0 = 1; b.x1 = 0; }
                 else
                 {
                     auto tl = [](double p, int ts, int nt, bool up) { double t = __builtin_floor(p / ts); if (t < 0) t = 0; if (t > nt - 1) t = nt - 1; (void)up; return (int32_t)t; };
@@ -495,6 +544,12 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
 
     T.assign((size_t)n_tiles, QR_NULL);
     if (ent.empty()) return QR_OK;
+    if (const char *vb = getenv("QR_VERBOSE"))
+        if (atoi(vb) >= 2)
+            for (const BinEntry &b : ent)
+                if (!b.marker)
+                    fprintf(stderr, "bin entry: surface %d tiles %d (x %d..%d, y %d..%d)\n", b.simd,
+                            b.x1 < b.x0 ? 0 : (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1), b.x0, b.x1, b.y0, b.y1);
 
     BinEntry *d_ent = nullptr; int32_t *d_cnt = nullptr, *d_off = nullptr, *d_heads = nullptr; qr_elem *d_cells = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_ent); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_heads); (void)hipFree(d_cells); };
