@@ -593,6 +593,9 @@ extern "C" int qr_scene_upload(const void *blob, uint64_t size, int device, qr_d
 extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, uint32_t flags, qr_device_scene **out)
 {
     if (blob == nullptr || out == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    const bool ph_verbose = getenv("QR_VERBOSE") && atoi(getenv("QR_VERBOSE")) >= 2;
+    double ph_t = now_ms();
+    auto phase = [&](const char *name) { if (ph_verbose) { const double t = now_ms(); fprintf(stderr, "upload phase %-12s %.3f ms\n", name, t - ph_t); ph_t = t; } };
     if (getenv("QR_REBIN") && atoi(getenv("QR_REBIN")) != 0) flags |= QR_UPLOAD_REBIN_TILES;
     qr_scene_view v;
     int rc = qr_scene_view_init(&v, blob, size);
@@ -715,6 +718,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     std::vector<int32_t> T(v.tiles, v.tiles + v.hdr->n_tiles);
     qr_frame frm = *v.frame;
 
+    phase("validate");
     /* ---- 1. build every device array on the host ---------------------------------------- */
 
     /* surfaces: repack qr_surface (256 B, snapshot layout) into DSurf (128 B, hot part first)
@@ -762,6 +766,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
         d.flags = f;
     }
 
+    phase("surfaces");
     /* bounding spheres + cull flag (bit 2 of a surface-list cell's kind) */
     std::vector<BSphere> bsph(n_srf + 1);
     memset(bsph.data(), 0, bsph.size() * sizeof(BSphere));
@@ -821,6 +826,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     }
     for (int i = 0; i < n_srf; i++) for (int k = 0; k < 4; k++) dshade[i].lst[k] = v.srf[i].lst[k];
 
+    phase("bounds+cells");
     /* wave schedule: one entry per wave footprint (8x8 / 8x4 / 4x4 pixels) */
     const int fw = frm.fsaa == 2 ? 4 : 8, fh = frm.fsaa == 0 ? 8 : 4;
     const int nbx = (frm.frm_w + fw - 1) / fw, nby = (frm.frm_h + fh - 1) / fh;
@@ -840,41 +846,50 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
                     if (!(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] |= 2;
                 }
             }
-        std::vector<uint32_t> heavy, light;
-        /* enumerate footprints tile by tile (32x8 pixel groups) to keep neighbours together */
+        /* enumerate footprints tile by tile (32x8 pixel groups) to keep neighbours together; entries are
+         * {footprint | heaviness, tile-list head}: the head when all pixels of the footprint lie in one tile
+         * (always, for the engine's 32x8 tiles), so that the wave needs no per-lane tile lookup.  This runs
+         * every frame in the drop-in path: no divisions in the common case, no reallocation. */
         const int gx = 32 / fw, gy = 8 / fh;
+        const bool nest = frm.tile_w == 32 && frm.tile_h == 8;      /* group (tx, ty) IS tile (tx, ty) */
+        std::vector<uint32_t> hv_ent, lt_ent;
+        hv_ent.reserve((size_t)nbx * nby / 4 + 16); lt_ent.reserve((size_t)nbx * nby * 2 + 16);
         for (int ty = 0; ty * gy < nby; ty++)
             for (int tx = 0; tx * gx < nbx; tx++)
+            {
+                int g_hv = 0; int32_t g_head = QR_PER_LANE_TILE;
+                if (nest && tx < frm.tls_row && ty < frm.tls_col)
+                {
+                    const size_t t = (size_t)ty * frm.tls_row + tx;
+                    g_hv = tile_heavy[t]; g_head = T[t];
+                }
                 for (int j = 0; j < gy; j++)
                     for (int i = 0; i < gx; i++)
                     {
                         const int bx = tx * gx + i, by = ty * gy + j;
                         if (bx >= nbx || by >= nby) continue;
-                        const int tlx = (bx * fw) / frm.tile_w, tly = (by * fh) / frm.tile_h;
-                        const int hv = (tlx < frm.tls_row && tly < frm.tls_col) ? tile_heavy[(size_t)tly * frm.tls_row + tlx] : 0;
+                        int hv = g_hv; int32_t head = g_head;
+                        if (!nest)
+                        {
+                            const int x0 = bx * fw, y0 = by * fh;
+                            const int x1 = std::min(x0 + fw - 1, frm.frm_w - 1), y1 = std::min(y0 + fh - 1, frm.frm_h - 1);
+                            const int tlx = x0 / frm.tile_w, tly = y0 / frm.tile_h;
+                            const bool in = tlx < frm.tls_row && tly < frm.tls_col;
+                            hv = in ? tile_heavy[(size_t)tly * frm.tls_row + tlx] : 0;
+                            head = QR_PER_LANE_TILE;
+                            if (in && tlx == x1 / frm.tile_w && tly == y1 / frm.tile_h) head = T[(size_t)tly * frm.tls_row + tlx];
+                        }
                         const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14) | ((uint32_t)(hv & 3) << 30);
-                        (hv ? heavy : light).push_back(ent);
+                        std::vector<uint32_t> &dst = hv ? hv_ent : lt_ent;
+                        dst.push_back(ent); dst.push_back((uint32_t)head);
                     }
-        heavy.insert(heavy.end(), light.begin(), light.end());
-        /* second word: the footprint's tile-list head when all its pixels lie in one tile (always, for the
-         * engine's 32x8 tiles), so that the wave needs no per-lane tile lookup */
-        order.reserve(heavy.size() * 2);
-        for (uint32_t ent : heavy)
-        {
-            const int bx = (int)(ent & 0x3FFFu), by = (int)((ent >> 14) & 0x3FFFu);
-            const int x0 = bx * fw, y0 = by * fh;
-            const int x1 = std::min(x0 + fw - 1, frm.frm_w - 1), y1 = std::min(y0 + fh - 1, frm.frm_h - 1);
-            int32_t head = QR_PER_LANE_TILE;
-            if (x0 / frm.tile_w == x1 / frm.tile_w && y0 / frm.tile_h == y1 / frm.tile_h)
-            {
-                const int tlx = x0 / frm.tile_w, tly = y0 / frm.tile_h;
-                if (tlx < frm.tls_row && tly < frm.tls_col) head = T[(size_t)tly * frm.tls_row + tlx];
             }
-            order.push_back(ent); order.push_back((uint32_t)head);
-        }
+        order.swap(hv_ent);
+        order.insert(order.end(), lt_ent.begin(), lt_ent.end());
     }
     const size_t n_sched = order.size() / 2;
 
+    phase("schedule");
     /* ---- 2. one device allocation; arrays padded by one zero record so that masked-off
      *         lanes may read index 0 of an empty array ------------------------------------ */
     size_t o_srf = 0;
@@ -936,6 +951,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     qr_device_scene *s = new qr_device_scene();     /* value-initialised: plain members are zero */
     s->device = device;
     s->hdr = *v.hdr;
+    phase("stage");
     const double tm0 = now_ms();
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e != hipSuccess) { delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -950,6 +966,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
 #endif
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     s->blob_bytes = total;
+    phase("device");
 
     uint8_t *d = (uint8_t *)s->d_blob;
     s->sc.srf = (const DSurf *)(d + o_srf);
