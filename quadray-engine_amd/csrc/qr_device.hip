@@ -13,6 +13,9 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <vector>
 #include <mutex>
 #include <map>
@@ -1334,11 +1337,39 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
 
 /* per-thread device frame + pinned staging buffer, kept between calls: the drop-in path renders a frame
  * per call, and hipMalloc/hipFree plus a pageable 8 MB copy cost more than the kernel itself */
+#define QR_COPY_CHUNKS 4
+
+/* copy into the caller's frame with non-temporal stores: the frame is written once and not read by us, so
+ * read-for-ownership traffic and cache pollution of a plain memcpy are avoided (8 MB per frame) */
+static void copy_streaming(void *dst, const void *src, size_t n)
+{
+#if defined(__SSE2__)
+    uint8_t *d = (uint8_t *)dst; const uint8_t *s = (const uint8_t *)src;
+    const size_t head = (16 - ((uintptr_t)d & 15)) & 15;
+    if (n < 4096 || head >= n) { memcpy(dst, src, n); return; }
+    memcpy(d, s, head); d += head; s += head; n -= head;
+    const size_t blocks = n / 64;
+    for (size_t i = 0; i < blocks; i++)
+    {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(s + 0)), b = _mm_loadu_si128((const __m128i *)(s + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i *)(s + 32)), e = _mm_loadu_si128((const __m128i *)(s + 48));
+        _mm_stream_si128((__m128i *)(d + 0), a); _mm_stream_si128((__m128i *)(d + 16), b);
+        _mm_stream_si128((__m128i *)(d + 32), c); _mm_stream_si128((__m128i *)(d + 48), e);
+        s += 64; d += 64;
+    }
+    _mm_sfence();
+    memcpy(d, s, n - blocks * 64);
+#else
+    memcpy(dst, src, n);
+#endif
+}
+
 struct HostPathCache
 {
     int device = -1;
     void *d_frame = nullptr; size_t d_cap = 0;
     uint32_t *h_frame = nullptr; size_t h_cap = 0;
+    hipEvent_t ev[QR_COPY_CHUNKS] = {};
     ~HostPathCache()
     {
         /* the HIP runtime may already be shut down when thread-locals are destroyed at exit: leak */
@@ -1369,6 +1400,33 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
     }
     const bool whole = s->sc.row_begin == 0 && s->sc.row_end == h && s->sc.group_first == 0 && s->sc.group_stride == 1 && s->sc.thnum <= 1;
     hipError_t e = launch<false>(s, c.d_frame, nullptr, nullptr);
+    if (e == hipSuccess && whole && row_pixels == w && h >= 64)
+    {
+        /* compact whole frame: the copy back runs in QR_COPY_CHUNKS row bands, the DMA of band k+1 under
+         * the host memcpy of band k into the caller's frame */
+        if (c.ev[0] == nullptr) for (int k = 0; k < QR_COPY_CHUNKS; k++) if (hipEventCreateWithFlags(&c.ev[k], hipEventDisableTiming) != hipSuccess) c.ev[k] = nullptr;
+        bool ok = true;
+        for (int k = 0; k < QR_COPY_CHUNKS; k++) ok = ok && c.ev[k] != nullptr;
+        if (ok)
+        {
+            int y0[QR_COPY_CHUNKS + 1];
+            for (int k = 0; k <= QR_COPY_CHUNKS; k++) y0[k] = (int)((long long)h * k / QR_COPY_CHUNKS);
+            for (int k = 0; k < QR_COPY_CHUNKS && e == hipSuccess; k++)
+            {
+                const size_t off = (size_t)y0[k] * w, n = (size_t)(y0[k + 1] - y0[k]) * w * 4;
+                e = hipMemcpyAsync(c.h_frame + off, (const uint32_t *)c.d_frame + off, n, hipMemcpyDeviceToHost, nullptr);
+                if (e == hipSuccess) e = hipEventRecord(c.ev[k], nullptr);
+            }
+            for (int k = 0; k < QR_COPY_CHUNKS && e == hipSuccess; k++)
+            {
+                e = hipEventSynchronize(c.ev[k]);
+                const size_t off = (size_t)y0[k] * w, n = (size_t)(y0[k + 1] - y0[k]) * w * 4;
+                if (e == hipSuccess) copy_streaming(frame_host + off, c.h_frame + off, n);
+            }
+            if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+            return QR_OK;
+        }
+    }
     if (e == hipSuccess) e = hipMemcpy(c.h_frame, c.d_frame, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
     /* copy only the rows this call owns, honouring a negative stride (bottom-up
