@@ -50,4 +50,9 @@ if "SQ_WAVE_CYCLES" in c and "SQ_INSTS_VALU" in c:
                              valu_issue_quadcycles_per_simd=c["SQ_ACTIVE_INST_VALU"] / 1024,
                              source=f"profiles/{rnd}_final_demo1_1080p.txt")
     json.dump(va, open(os.path.join(P, "valu.json"), "w"), indent=1, sort_keys=True)
+import shutil
+for f in glob.glob(os.path.join(G, f"{tag}_bench_*.json")):
+    name = os.path.basename(f)[len(tag) + 1:]
+    if name != "bench_n1.json" and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(P, f"{rnd}_{name}"))
 print("".join(out[:12]))
