@@ -995,7 +995,10 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
             n_real++; if (q.clip != QR_NULL) any_clip = true;
         }
         const char *dv = getenv("QR_DIV");
-        s->divergent = !any_clip && (dv ? atoi(dv) != 0 : n_real >= 1024);
+        /* it pays when a wave's rays share little: many objects per pixel (10 000 quadrics: +10 % at
+         * 1920x1080, -12 % at 7680x4320 where an object covers 16 times the pixels) */
+        s->divergent = !any_clip && (dv ? atoi(dv) != 0
+                                        : n_real >= 1024 && (long long)n_real * 500 > (long long)frm.frm_w * frm.frm_h);
     }
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
