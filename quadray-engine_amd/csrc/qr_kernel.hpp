@@ -10,19 +10,21 @@
  *
  * How it is organised for CDNA4 (this is not the reference's structure):
  *   - one lane = one ray (sample); a 64-lane wavefront = one 8x8 pixel block
- *     (4x4 / 8x4 pixels under 4x / 2x FSAA), a 256-thread workgroup = one
- *     32x8 reference tile, so the four waves share the tile's object list.
+ *     (4x4 / 8x4 pixels under 4x / 2x FSAA) and is its own workgroup; waves take
+ *     entries of a host-computed schedule (footprints that can recurse first and
+ *     with issue priority, the tile-list head in the entry, empty tiles leave at once).
  *   - WAVE-PACKET TRAVERSAL: lanes of a wave that walk the same list walk it
- *     together; the element index is wave-uniform, so element and surface
+ *     together; the element index is wave-uniform, so list cells and surface
  *     records are fetched with SCALAR loads (constant address space) into
  *     SGPRs and only per-ray quantities live in VGPRs.  Lanes with different
  *     lists (secondary rays leaving different surfaces) are served group by
  *     group (__ballot / readfirstlane) - the wave-level analogue of the
  *     reference's CHECK_MASK NONE/FULL packet early-outs (rtbase.h:1209).
- *   - the walk is SOFTWARE PIPELINED: while element i is intersected, the
- *     20-dword hot record of element i+1 and the list cell of element i+2 are
- *     already in flight, so the two dependent scalar-load latencies per
- *     element are off the critical path at 2-3 waves per SIMD.
+ *   - per cell, a conservative bounding-sphere test (ours) lets the wave skip
+ *     elements no ray can meet; bounding-volume arrays are skipped per ray and,
+ *     when no ray of the group enters one, jumped over by the whole wave.
+ *   - a DIVERGENT variant (walk_div) walks every lane's list independently with
+ *     vector loads, for scenes of thousands of small objects.
  *   - DEFERRED SHADING: the reference shades every hit that passes the depth
  *     test while it walks a list (overdraw); shading has no effect on the walk
  *     and fully overwrites the lane's colour, so walking first (keeping the
