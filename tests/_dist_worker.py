@@ -38,6 +38,12 @@ def main():
     ex.exchange(frames, final)
     whole, _, _ = qr_oracle.render(blob, depth=rank, threads=1)
     ok = bool((final.numpy().view(np.uint32) == whole).all())
+    # several steps in ONE grouped exchange (what bench.py does every three steps): step s carries the frames
+    # with every pixel XOR s, each must arrive intact in its own target
+    steps = [([fr ^ s for fr in frames], torch.zeros((h, w), dtype=torch.int32)) for s in range(3)]
+    ex.exchange_many(steps)
+    for s, (_, fin) in enumerate(steps):
+        ok = ok and bool(((fin ^ s).numpy().view(np.uint32) == whole).all())
     # every row of every frame is rendered by exactly one rank
     cover = torch.zeros((world, h), dtype=torch.int32)
     for f in range(world):
