@@ -162,7 +162,11 @@ __device__ __forceinline__ float rsq(float x) { return 1.0f / __builtin_sqrtf(x)
  * words the same logic is v_cmp + v_cndmask + v_and.  The empty asm keeps the optimiser from
  * folding the words back into i1 logic.
  */
+#ifdef QR_LM_FOLD
+__device__ __forceinline__ u32 LM(bool c) { return c ? 0xFFFFFFFFu : 0u; }
+#else
 __device__ __forceinline__ u32 LM(bool c) { u32 x = c ? 0xFFFFFFFFu : 0u; asm("" : "+v"(x)); return x; }
+#endif
 
 __device__ __forceinline__ int32_t cvt_floor(float x)
 {
