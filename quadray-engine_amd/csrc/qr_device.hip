@@ -985,20 +985,12 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->h_order = order;
     s->sc.nested = nested ? 1 : 0;
     {
-        /* Divergent variant: for scenes of very many small objects, where the rays of a wave share little.
-         * It has no custom-clipper loop, so scenes with clip lists never take it.  QR_DIV=0|1 overrides. */
-        bool any_clip = false; int n_real = 0;
-        for (int i = 0; i < n_srf; i++)
-        {
-            const qr_surface &q = v.srf[i];
-            if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) continue;
-            n_real++; if (q.clip != QR_NULL) any_clip = true;
-        }
+        /* Divergent variant (walk_div): opt-in with QR_DIV=1.  Bit-exact on every fixture, but an iteration
+         * made of dependent vector loads costs several scalar ones: it shortens the deepest waves' chains
+         * (demo2 1080p: 1.04 ms per isolated launch against 1.13) and loses on throughput everywhere measured,
+         * including the 10 000-quadric scene once the per-lane clipper loop raised its register need to 154. */
         const char *dv = getenv("QR_DIV");
-        /* it pays when a wave's rays share little: many objects per pixel (10 000 quadrics: +10 % at
-         * 1920x1080, -12 % at 7680x4320 where an object covers 16 times the pixels) */
-        s->divergent = !any_clip && (dv ? atoi(dv) != 0
-                                        : n_real >= 1024 && (long long)n_real * 500 > (long long)frm.frm_w * frm.frm_h);
+        s->divergent = dv != nullptr && atoi(dv) != 0;
     }
     s->sc.stats = s->d_counters + 4;
     s->sc.frp = (const qr_frame *)(d + o_frm);
@@ -1132,7 +1124,7 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
     static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
                                     return (w == 2 || w == 3 || w == 4) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
-    if (s->divergent)    hipLaunchKernelGGL((qr_render_kernel<COUNT, 4, true>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
+    if (s->divergent)    hipLaunchKernelGGL((qr_render_kernel<COUNT, 3, true>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     else if (waves == 4) hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<COUNT, 3>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);
     else                 hipLaunchKernelGGL((qr_render_kernel<COUNT, 2>), grid, dim3(QR_BLOCK), 0, st, sc, f, ids_dev, s->d_counters);

@@ -446,7 +446,109 @@ __device__ __forceinline__ u32 clip(const DevScene &sc, const Hot &s, SP P,
 #endif
     /* custom clipping, 1931-2151 */
     int e = s.clip;
-    if (DIV) e = QR_NULL;        /* the divergent kernel is only launched for scenes without custom clippers */
+    if (DIV)
+    {
+        /* the same loop with a per-lane clipper list: every lane steps through its own cells (vector loads),
+         * `continue` of the wave-uniform version becomes `break` out of the one-trip do-block */
+        int redx = QR_NULL;
+        const int local_lst = P->trnode;
+        u32 c_acc = 0;
+        V3 cxyz = {0.0f, 0.0f, 0.0f}, cijk = {0.0f, 0.0f, 0.0f};
+        if (!__any(m != 0)) e = QR_NULL;
+        while (__any(e != QR_NULL))
+        {
+            if (e != QR_NULL)
+            do
+            {
+                const DCell dc_ = sc.elm[e];
+                qr_elem el; el.simd = dc_.simd; el.data = dc_.data; el.next = dc_.next; el.kind = dc_.kind;
+                const int ecur = e;
+                e = el.next;
+                if (el.simd == QR_NULL)
+                {
+                    if (el.data > 0) { m = ~m & c_acc; }
+                    else             { c_acc = m; m = DF_CDEF(fl) != 0 ? 0xFFFFFFFFu : 0u; }
+                    break;
+                }
+                const DSurf *kp = sc.srf + el.simd;
+                const Hot k = ld_hot5(kp);
+                const u32 kf = k.flags;
+                const int ktrm = (int)DF_TRM(kf);
+                const bool karr = DF_ARRAY(kf) != 0;
+                bool have_vec = false;
+                if (!karr)
+                {
+                    if (redx != QR_NULL)
+                    {
+                        cijk.x = cxyz.x - k.pos0;
+                        cijk.y = cxyz.y - k.pos1;
+                        cijk.z = cxyz.z - k.pos2;
+                        if (ecur == redx) redx = QR_NULL;
+                        have_vec = true;
+                    }
+                }
+                else if (el.simd == local_lst)
+                {
+                    cxyz.x = nijk.x + s.pos0;
+                    cxyz.y = nijk.y + s.pos1;
+                    cxyz.z = nijk.z + s.pos2;
+                    redx = el.data;
+                    break;
+                }
+                if (!have_vec)
+                {
+                    V3 d;
+                    d.x = hit.x - k.pos0;
+                    d.y = hit.y - k.pos1;
+                    d.z = hit.z - k.pos2;
+                    cxyz = d;
+                    if (ktrm != 0)
+                    {
+                        V3 p = xform(kp, ktrm, d);
+                        if (karr)
+                        {
+                            cxyz = p;
+                            redx = el.data;
+                            break;
+                        }
+                        cijk = p;
+                    }
+                }
+                const V3 cv = DF_SHIFT(kf) ? cijk : cxyz;
+                const int ckind = (int)DF_CKIND(kf);
+                float f4 = 0.0f, f5, f6, f1, f2, f3;
+                bool ok = true;
+                if (ckind == 1)
+                {
+                    f4 = fxor(vget(cv, (int)DF_MAP(kf, 2)), DF_SGN(kf, 2));
+                }
+                else if (ckind == 2)
+                {
+                    f4 = cv.x; f1 = k.scj0; f1 = f1 + f1; f1 = f1 * f4;
+                    f4 = f4 * f4; f4 = f4 * k.sci0; f4 = f4 - f1;
+                    f5 = cv.y; f2 = k.scj1; f2 = f2 + f2; f2 = f2 * f5;
+                    f5 = f5 * f5; f5 = f5 * k.sci1; f5 = f5 - f2;
+                    f6 = cv.z; f3 = k.scj2; f3 = f3 + f3; f3 = f3 * f6;
+                    f6 = f6 * f6; f6 = f6 * k.sci2; f6 = f6 - f3;
+                    f4 = f4 - k.sci3; f4 = f4 + f5; f4 = f4 + f6;
+                }
+                else if (ckind == 3)
+                {
+                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * k.sci0;
+                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * k.sci1;
+                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * k.sci2;
+                    f4 = f4 - k.sci3; f4 = f4 + f5; f4 = f4 + f6;
+                }
+                else
+                {
+                    ok = false;
+                }
+                if (ok) m &= LM(el.data < 0 ? cge(f4, 0.0f) : cle(f4, 0.0f));
+            }
+            while (0);
+        }
+        e = QR_NULL;
+    }
     if (e != QR_NULL && __any(m != 0))
     {
         int redx = QR_NULL;
