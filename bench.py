@@ -311,8 +311,10 @@ def main():
         value = total_rays / dt / 1e6
         bw = {0: 32, 1: 16, 2: 8}[scn.info.fsaa]
         n_wg = ((W + bw - 1) // bw) * n_groups
-        # bytes_alg = 4*W*H (frame write) + n_workgroups * scene_bytes, scene_bytes = the
-        # surface + material + light records one workgroup needs (128 B device surface records + 32 B shading
+        # bytes_alg = 4*W*H (frame write) + n_workgroups * scene_bytes with one workgroup per
+        # 32x8 reference tile (the kernel now runs one wave per workgroup; the tile count is kept as the unit so
+        # that the figure does not grow with the launch shape), scene_bytes = the
+        # surface + material + light records one tile's rays need (128 B device surface records + 32 B shading
         # records, 128 B materials, 64 B lights)
         scene_bytes = scn.info.n_srf * (128 + 32) + scn.info.n_mat * 128 + scn.info.n_lgt * 64
         alg_bytes = 4 * W * H + n_wg * scene_bytes

@@ -1660,7 +1660,7 @@ __device__ __forceinline__ void render_wave(const DevScene &sc, const u32 ord, c
     /* wave footprint: 8x8 pixels (no AA), 8x4 (2x), 4x4 (4x).  Every WAVE takes one entry of
      * the host-computed schedule (footprints that can spawn deep recursion first, so that their
      * long waves overlap the bulk instead of forming a tail); consecutive entries are
-     * neighbouring footprints, so the waves of a workgroup still share tile lists. */
+     * neighbouring footprints, so waves running side by side still share tile lists in the scalar cache. */
     const int fw = fsaa == 2 ? 4 : 8, fh = fsaa == 0 ? 8 : 4;
     (void)wv; (void)gw;
     /* footprints that can recurse get issue priority: the frame ends with the slowest of them, and while
