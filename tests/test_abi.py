@@ -90,3 +90,20 @@ def test_upload_rejects_oversized_frame_and_broken_lists(qr):
     struct.pack_into("<i", cyc, off_elm + 16 * e + 8, head)                 # last cell's next -> head
     rc, msg = err_of(bytes(cyc))
     assert rc == -1 and "cyclic" in msg, msg
+
+
+@pytest.mark.parametrize("name", ["demo01_160", "demo02_160_gf_aa4", "test13_160"])
+def test_walker_reproduces_golden_snapshot(name, tmp_path):
+    """The flattener (product code, csrc/qr_walker.cpp) run inside the unmodified reference engine through the
+    drop-in shim writes byte for byte the snapshot committed under tests/golden/ (needs oracle/_ref, which
+    exists in the build container and travels to the GPU box)."""
+    import json, subprocess
+    shim = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+    if not os.path.exists(shim):
+        pytest.skip("oracle/_ref/qr_ref_shim is not built")
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))[name]
+    (tmp_path / "dump").mkdir()
+    out = tmp_path / "s.qrs"
+    cmd = [shim, "--scene", man["scene"], "-w", str(man["w"]), "-h", str(man["h"]), "--snapshot", str(out)] + man["args"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True, timeout=120)
+    assert out.read_bytes() == load_blob(name)
