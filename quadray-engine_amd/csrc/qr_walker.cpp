@@ -17,6 +17,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 
 namespace {
@@ -91,6 +94,11 @@ public:
         const size_t mask = keys.size() - 1;
         for (size_t j = slot(key, mask); keys[j]; j = (j + 1) & mask) if (keys[j] == key) return &vals[j];
         return nullptr;
+    }
+    void reserve(size_t n)
+    {
+        size_t cap = 1024; while (cap < 2 * n) cap *= 2;
+        if (cap > keys.size()) { std::vector<uint64_t> k(cap, 0); std::vector<int32_t> v(cap, 0); keys.swap(k); vals.swap(v); used = 0; }
     }
     void put(uint64_t key, int32_t val)
     {
@@ -224,10 +232,16 @@ struct Walker
         if (head == 0) return QR_NULL;
         if (const int32_t *known = elm_ix.find(head)) return *known;
 
+        /* cells new to this walk get consecutive indices from `base`, so inside the run `next` is the
+         * following index and only the run's exit (NULL or a cell met before) needs a lookup: this runs
+         * for every tile list of every frame in the drop-in path */
         std::vector<uint64_t> fresh;
+        fresh.reserve(16);
+        const int32_t base = (int32_t)elm.size();
+        int32_t exit_ix = QR_NULL;
         for (uint64_t p = head; p != 0; )
         {
-            if (elm_ix.find(p)) break;
+            if (const int32_t *k = elm_ix.find(p)) { exit_ix = *k; break; }
             int32_t ix = (int32_t)elm.size();
             elm_ix.put(p, ix);
             qr_elem e; e.simd = QR_NULL; e.data = QR_NULL; e.next = QR_NULL; e.kind = 0;
@@ -237,11 +251,12 @@ struct Walker
             if (elm.size() > (size_t)64 * 1024 * 1024) { err = "element list too long / cyclic"; return QR_NULL; }
         }
 
-        for (uint64_t p : fresh)
+        for (size_t fi = 0; fi < fresh.size(); fi++)
         {
+            const uint64_t p = fresh[fi];
             ElemRaw r = rd_elem(a, p);
             qr_elem e;
-            e.next = r.next ? elm_ix.at(r.next) : QR_NULL;
+            e.next = fi + 1 < fresh.size() ? base + (int32_t)fi + 1 : exit_ix;
             e.kind = 0;
             e.data = QR_NULL;
             e.simd = QR_NULL;
@@ -293,19 +308,19 @@ struct Walker
                 break;
             }
             }
-            elm[elm_ix.at(p)] = e;
+            elm[(size_t)base + fi] = e;
         }
 
         if (kind == LIST_LIGHTS)
         {
-            for (uint64_t p : fresh)
+            for (size_t fi = 0; fi < fresh.size(); fi++)
             {
-                ElemRaw r = rd_elem(a, p);
+                ElemRaw r = rd_elem(a, fresh[fi]);
                 int32_t sh = walk_list((uint64_t)r.data, LIST_SURFACES);
-                elm[elm_ix.at(p)].data = sh;
+                elm[(size_t)base + fi].data = sh;
             }
         }
-        return elm_ix.at(head);
+        return base;
     }
 
     void flatten_surface(uint64_t p)
@@ -483,16 +498,24 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     f.tls_col = (frm_h + tile_h - 1) / tile_h;
     f.index = index; f.thnum = thnum;
 
+    const bool ph = getenv("QR_VERBOSE") && atoi(getenv("QR_VERBOSE")) >= 2;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double pt = now();
+    auto phase = [&](const char *n) { if (ph) { const double t = now(); fprintf(stderr, "flatten phase %-10s %.3f ms\n", n, t - pt); pt = t; } };
     /* primary lists: per-tile heads (tracer.cpp:1182-1194, 1328-1339) and inf_LST */
     std::vector<int32_t> tiles((size_t)f.tls_row * f.tls_col, QR_NULL);
+    w.elm_ix.reserve(tiles.size() * 2 + 4096);          /* before anything is in it: no rehash while walking */
+    w.elm.reserve(tiles.size() * 2 + 4096);
     const uint8_t *tl = (const uint8_t *)(uintptr_t)p_tiles;
     for (size_t i = 0; i < tiles.size() && w.err.empty(); i++)
     {
         uint64_t head = rd_ptr(a, tl, i * a.ps);
         tiles[i] = w.walk_list(head, LIST_SURFACES);
     }
+    phase("tiles");
     f.clist = w.walk_list(p_lst, LIST_SURFACES);
     w.drain();
+    phase("surfaces");
     if (!w.err.empty()) { err = w.err; return QR_ERR_ARG; }
 
     /* assemble blob */
@@ -523,5 +546,6 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     if (!w.elm.empty())    memcpy(out.data() + h.off_elm, w.elm.data(), w.elm.size() * sizeof(qr_elem));
     if (!tiles.empty())    memcpy(out.data() + h.off_tiles, tiles.data(), tiles.size() * 4);
     if (!w.texels.empty()) memcpy(out.data() + h.off_texels, w.texels.data(), w.texels.size() * 4);
+    phase("assemble");
     return QR_OK;
 }
