@@ -109,7 +109,10 @@ def test_gpu_drop_in_through_reference_engine():
     os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
     for args in (["--scene", "demo01", "-w", "640", "-h", "480"],
                  ["--scene", "demo02", "-w", "320", "-h", "240", "--gamma", "--fresnel", "--fsaa", "4", "-t", "3000"],
-                 ["--scene", "test13", "-w", "200", "-h", "150", "--opts", "none"]):
+                 ["--scene", "test13", "-w", "200", "-h", "150", "--opts", "none"],
+                 # the engine's own thread pool: qr_render0 entered concurrently from 4 threads, each
+                 # owning every fourth row (index / thnum, tracer.cpp:1144-1145)
+                 ["--scene", "demo03", "-w", "333", "-h", "211", "--threads", "4", "--fsaa", "2"]):
         out = subprocess.run([exe] + args + ["--gpu"], cwd=tmp, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
