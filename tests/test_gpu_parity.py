@@ -187,6 +187,8 @@ def _recamera(blob, seed):
     for o in (1, 4, 7):
         fr[o:o + 3] = R @ fr[o:o + 3]
     fr[25:28] += rng.uniform(-4.0, 4.0, size=3).astype(np.float32)
+    fi[29] = int(rng.integers(0, 11))                               # recursion depth 0..10
+    fr[24] = np.float32(rng.choice([0.0, 0.5, 1.0, 2.0]))           # near clip t_min
     fi[34], fi[35], fi[36], fi[37] = fi[31], fi[32], 1, 1          # tile = frame
     b[off_frame:off_frame + 196] = fr.tobytes()
     struct.pack_into("<I", b, 4 * 8, 1)                             # n_tiles
