@@ -232,6 +232,20 @@ def _jitter_scene(blob, seed):
         s[i, 0:3] += rng.uniform(-0.4, 0.4, size=3).astype(np.float32)
         if si[i, 34] != 1:
             s[i, 27] *= np.float32(rng.uniform(0.85, 1.15))
+    # every transformed array gets an extra random rotation and a little shear; its members carry a copy of
+    # the array's matrix rows (tci/tcj/tck), so they receive the same new rows
+    for t in range(n_srf):
+        if si[t, 37] >= 0 or si[t, 15] < 2:
+            continue
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        th = rng.uniform(-0.5, 0.5)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K + rng.uniform(-0.05, 0.05, size=(3, 3))
+        M = np.stack([s[t, 12:15], s[t, 16:19], s[t, 20:23]]).astype(np.float64)
+        M2 = (M @ R).astype(np.float32)
+        for i in range(n_srf):
+            if si[i, 39] == t and si[i, 15] >= 2:
+                s[i, 12:15], s[i, 16:19], s[i, 20:23] = M2[0], M2[1], M2[2]
     b[off_srf:off_srf + s.nbytes] = s.tobytes()
     return bytes(b)
 
