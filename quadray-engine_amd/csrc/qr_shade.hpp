@@ -1,0 +1,468 @@
+/*
+ * qr_shade.hpp - device code, shading of the final hit of a walk (tracer.cpp:2166-3930 without the child
+ * packets): normal, texture, lights with shadow traversals, refraction + Fresnel, reflection + Fresnel.
+ * Included by qr_kernel.hpp after qr_walk.hpp.
+ */
+#ifndef QR_SHADE_HPP
+#define QR_SHADE_HPP
+
+/* ------------------------------------------------------------------------ */
+/* shading of the final hit, tracer.cpp:2166-3930 without the child packets  */
+/* ------------------------------------------------------------------------ */
+
+struct Frame
+{
+    float col[3];
+    float c_trn, c_rfl, x0;
+    float rdir[3];
+    float hit[3];
+    float loc[3];
+    int   meta;             /* si << 4 | side << 3 | rf << 2 | phase (1 TR, 2 RF) */
+};
+
+struct Shaded
+{
+    V3 col;                 /* local colour after lights                      */
+    V3 hit;                 /* world hit = child origin                       */
+    V3 loc;                 /* local hit = child's ploc                       */
+    V3 tdir;                /* refraction child direction (ctx_NEW after TR)  */
+    V3 rdir;                /* reflection child direction (ctx_NEW after RF)  */
+    float c_trn, c_rfl, x0;
+    bool want_tr;           /* refraction child exists (M_TRN, not opaque)    */
+    bool want_rf;           /* reflection pass applies (RF_ini reached)       */
+    int  lst_tr, lst_rf;
+};
+
+struct Counters { u32 primary, shadow, reflect, refract; };
+
+/* state of the enclosing recursion that only has to survive a shade() call */
+struct Outer { V3 ret; int hit_id, sp, mode; };
+
+template <bool COUNT, bool DIV>
+__device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r, const Hit &h,
+                                      Shaded &o, Counters &cnt)
+{
+    /* per-lane (divergent) material data; everything below is lane-private
+     * except the wave-wide shadow traversals in the light loop */
+    const int si = act ? h.si : 0;
+    const int side = h.side;
+    const DSurf *__restrict__ s = &sc.srf[si];
+    const DShade *__restrict__ sd = &sc.shd[si];
+    const FrmP fr = c_frm(sc);
+
+    V3 nrm = {0, 0, 1};
+    V3 tex = {0, 0, 0};
+    V3 col = {0, 0, 0};
+    V3 hit = {0, 0, 0};
+    int props = 0;
+    int mi = 0;
+    int le = QR_NULL;
+
+    if (act)
+    {
+        const float t = h.t;
+        float x0, x1, x2, x3, x4, x5, x6;
+        x4 = r.dir.x * t; hit.x = x4 + r.org.x;
+        x5 = r.dir.y * t; hit.y = x5 + r.org.y;
+        x6 = r.dir.z * t; hit.z = x6 + r.org.z;
+
+        props = side | (side ? s->props1 : s->props0);
+        mi = sd->mat[side];
+        const u32 fl = s->flags;
+        const u32 tside = side ? QR_SMASK : 0u;
+        const int has_trm = (int)DF_TRM(fl);
+        const int nkind = (int)DF_NKIND(fl);
+        float tu = 0.0f, tv = 0.0f;
+        V3 ln = {0, 0, 0};                          /* normal in surface space */
+
+        if (nkind == 1)
+        {
+            /* PL_mat 4139-4193 */
+            if (props & QR_PROP_TEXTURE)
+            {
+                tu = fxor(vget(h.loc, (int)DF_MAP(fl, 0)), DF_SGN(fl, 0));
+                tv = fxor(vget(h.loc, (int)DF_MAP(fl, 1)), DF_SGN(fl, 1));
+            }
+            x6 = fxor(1.0f, tside);
+            vset(ln, (int)DF_MAP(fl, 2), fxor(x6, DF_SGN(fl, 2)));
+        }
+        else
+        {
+            /* QD_mat 4845-4905 / TP_mat 4280-4336 */
+            x4 = h.loc.x * s->sci[0]; x5 = h.loc.y * s->sci[1]; x6 = h.loc.z * s->sci[2];
+            if (nkind == 2)
+            {
+                x4 = x4 - s->scj[0]; x5 = x5 - s->scj[1]; x6 = x6 - s->scj[2];
+            }
+            x1 = x4 * x4; x2 = x5 * x5; x3 = x6 * x6;
+            x1 = x1 + x2; x1 = x1 + x3;
+            x0 = rsq(x1);
+            x0 = fxor(x0, tside);
+            ln.x = x4 * x0; ln.y = x5 * x0; ln.z = x6 * x0;
+        }
+        nrm = ln;
+        if (has_trm != 0)
+        {
+            /* MT_nrm 2184-2263: transposed trnode matrix */
+            const DSurf *__restrict__ tr = &sc.srf[s->trnode];
+            const int ttrm = (int)DF_TRM(tr->flags);
+            x1 = ln.x; x2 = ln.y; x3 = ln.z;
+            x4 = tr->tci[0] * x1;
+            x5 = tr->tcj[1] * x2;
+            x6 = tr->tck[2] * x3;
+            if (ttrm != 1)
+            {
+                x4 = x4 + tr->tcj[0] * x2;
+                x4 = x4 + tr->tck[0] * x3;
+                x5 = x5 + tr->tci[1] * x1;
+                x5 = x5 + tr->tck[1] * x3;
+                x6 = x6 + tr->tci[2] * x1;
+                x6 = x6 + tr->tcj[2] * x2;
+            }
+            if (ttrm != 2)
+            {
+                x1 = x4 * x4; x2 = x5 * x5; x3 = x6 * x6;
+                x1 = x1 + x2; x1 = x1 + x3;
+                x0 = rsq(x1);
+                x4 = x4 * x0; x5 = x5 * x0; x6 = x6 * x0;
+            }
+            nrm.x = x4; nrm.y = x5; nrm.z = x6;
+        }
+
+        /* MT_tex 2293-2327, PAINT_FRAG / PAINT_COLX 653-673 */
+        const qr_material *__restrict__ mt = &sc.mat[mi];
+        u32 toff = 0;
+        if (props & QR_PROP_TEXTURE)
+        {
+            x4 = mt->t_map[0] ? tv : tu;
+            x5 = mt->t_map[1] ? tv : tu;
+            x4 = x4 - mt->xoffs; x5 = x5 - mt->yoffs;
+            x4 = x4 * mt->xscal; x5 = x5 * mt->yscal;
+            const int32_t iu = cvt_floor(x4) & (int32_t)mt->xmask;
+            const int32_t iv = cvt_floor(x5) & (int32_t)mt->ymask;
+            toff = (u32)iu + ((u32)iv << (mt->yshft & 31));
+        }
+        const u32 texel = sc.texels[mt->tex + (int32_t)toff];
+        const u32 cmask = mt->cmask;
+        const float clampv = mt->clamp;
+        tex.x = (float)(int32_t)((texel >> 16) & cmask) / clampv;
+        tex.y = (float)(int32_t)((texel >> 8) & cmask) / clampv;
+        tex.z = (float)(int32_t)(texel & cmask) / clampv;
+        if (props & QR_PROP_GAMMA) { tex.x = tex.x * tex.x; tex.y = tex.y * tex.y; tex.z = tex.z * tex.z; }
+
+        if (props & QR_PROP_LIGHT)
+        {
+            col = tex;                              /* LT_set */
+        }
+        else
+        {
+            col.x = tex.x * fr->amb[0];
+            col.y = tex.y * fr->amb[1];
+            col.z = tex.z * fr->amb[2];
+            le = sd->lst[side * 2];
+        }
+    }
+
+    /* lights, 2758-3156: wave-wide loop, per-lane light elements */
+    while (__any(le != QR_NULL))
+    {
+        const bool has = le != QR_NULL;
+        const DCell cel = sc.elm[has ? le : 0];
+        qr_elem el; el.simd = cel.simd; el.data = cel.data; el.next = cel.next; el.kind = cel.kind;
+        const qr_light *__restrict__ lg = &sc.lgt[has ? el.simd : 0];
+        V3 L = {0, 0, 0};
+        float dot = 0.0f;
+        bool lm = false;
+        if (has)
+        {
+            float x1, x2, x3, x0;
+            x1 = lg->pos[0] - hit.x; L.x = x1; x1 = x1 * nrm.x;
+            x2 = lg->pos[1] - hit.y; L.y = x2; x2 = x2 * nrm.y;
+            x3 = lg->pos[2] - hit.z; L.z = x3; x3 = x3 * nrm.z;
+            x0 = x1; x0 = x0 + x2; x0 = x0 + x3;
+            dot = x0;
+            lm = clt(0.0f, x0);
+        }
+        Ray sr;
+        sr.org = hit; sr.dir = L; sr.tmin = 0.0f; sr.tmax = lg->t_max;
+        sr.list = el.data; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
+        Hit sh; bool occ;
+        if (COUNT) { if (lm) cnt.shadow++; }
+        if (QR_KNOB(2)) lm = false;
+        if (QR_KNOB(1)) occ = false; else
+        {
+#ifdef QR_X_NOSHADOW
+            occ = false; sh.si = 0;
+#else
+#ifdef QR_WAVETIME
+            const unsigned long long wt_a = __builtin_amdgcn_s_memrealtime();
+#endif
+            traverse<true, DIV>(sc, lm, sr, sh, occ);
+#ifdef QR_WAVETIME
+            if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+                sc.stats[28 + ((size_t)blockIdx.x * (QR_BLOCK / 64) + (threadIdx.x >> 6)) * QR_WT_SLOTS + 10] += __builtin_amdgcn_s_memrealtime() - wt_a;
+#endif
+#endif
+        }
+        if (lm && !occ)
+        {
+            const qr_material *__restrict__ mt = &sc.mat[mi];
+            float x0, x1, x2, x3, x4, x5, x6, x7;
+            x1 = L.x; x4 = x1 * x1;
+            x2 = L.y; x5 = x2 * x2;
+            x3 = L.z; x6 = x3 * x3;
+            x4 = x4 + x5; x4 = x4 + x6;
+            const float r2 = x4;
+            x0 = dot;
+            if (props & QR_PROP_DIFFUSE)
+            {
+                x6 = x4;
+                x5 = rsq(x4);
+                x4 = x5 * x6;
+                x6 = x6 * lg->a_qdr;
+                x4 = x4 * lg->a_lnr;
+                x6 = x6 + lg->a_cnt;
+                x6 = x6 + x4;
+                x4 = rsq(x6);
+                x6 = x0;
+                x0 = x0 * x4;
+                x0 = x0 * x5;
+                x0 = x0 * mt->l_dff;
+            }
+            else
+            {
+                x6 = x0;
+                x0 = 0.0f;
+            }
+            bool plain = false;
+            float spec = 0.0f;
+            if (props & QR_PROP_SPECULAR)
+            {
+                x4 = x6; x5 = x6;
+                x4 = x4 * nrm.x; x1 = x1 - x4; x1 = x1 - x4;
+                x5 = x5 * nrm.y; x2 = x2 - x5; x2 = x2 - x5;
+                x6 = x6 * nrm.z; x3 = x3 - x6; x3 = x3 - x6;
+                x4 = r.dir.x; x1 = x1 * x4; x4 = x4 * x4;
+                x5 = r.dir.y; x2 = x2 * x5; x5 = x5 * x5;
+                x6 = r.dir.z; x3 = x3 * x6; x6 = x6 * x6;
+                x6 = x6 + x4; x6 = x6 + x5;
+                x1 = x1 + x2; x1 = x1 + x3;
+                if (clt(0.0f, x1))
+                {
+                    x4 = r2;
+                    x5 = rsq(x6); x1 = x1 * x5;
+                    x5 = rsq(x4); x1 = x1 * x5;
+                    /* fixed-point 28.4 power, 2981-3039 */
+                    const u32 lpow = mt->l_pow;
+                    u32 pw = lpow & 0xF;
+                    x2 = x1; x4 = x1; x1 = 1.0f;
+                    while (pw != 0)
+                    {
+                        x4 = __builtin_sqrtf(x4);
+                        const u32 bit = pw & 0x8;
+                        pw = (pw << 1) & 0xF;
+                        if (bit) x1 = x1 * x4;
+                    }
+                    pw = lpow >> 4;
+                    if (pw != 0)
+                    {
+                        x3 = x1; x1 = 1.0f;
+                        do
+                        {
+                            const u32 bit = pw & 1;
+                            pw >>= 1;
+                            if (bit) x1 = x1 * x2;
+                            x2 = x2 * x2;
+                        }
+                        while (pw != 0);
+                        x1 = x1 * x3;
+                    }
+                    x1 = x1 * mt->l_spc;
+                    if (props & QR_PROP_METAL) { x0 = x0 + x1; }
+                    else { plain = true; spec = x1; }
+                }
+            }
+            if (!plain)
+            {
+                x1 = tex.x * lg->col[0];
+                x2 = tex.y * lg->col[1];
+                x3 = tex.z * lg->col[2];
+                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+            }
+            else
+            {
+                x7 = spec;
+                x1 = tex.x; x2 = tex.y; x3 = tex.z;
+                x4 = lg->col[0]; x5 = lg->col[1]; x6 = lg->col[2];
+                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+                x1 = x1 * x4; x2 = x2 * x5; x3 = x3 * x6;
+                x4 = x4 * x7; x5 = x5 * x7; x6 = x6 * x7;
+                x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
+                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+            }
+        }
+        le = has ? el.next : QR_NULL;
+    }
+
+    o.col = col; o.hit = hit; o.loc = h.loc;
+    o.tdir = {0, 0, 0}; o.rdir = {0, 0, 0};
+    o.c_trn = 0.0f; o.c_rfl = 0.0f; o.x0 = 0.0f;
+    o.want_tr = false; o.want_rf = false;
+    o.lst_tr = QR_NULL; o.lst_rf = QR_NULL;
+
+    if (act)
+    {
+        const qr_material *__restrict__ mt = &sc.mat[mi];
+        const float m_trn_c = mt->c_trn, m_rfl_c = mt->c_rfl;
+        float c_trn = m_trn_c, c_rfl = m_rfl_c;
+        float x0 = 0.0f, x1, x2, x3, x4 = 0.0f, x5, x6 = 0.0f, x7 = 0.0f;
+        bool m_trn = true;
+
+        /* transparency 3185-3552 */
+        if (!(props & QR_PROP_OPAQUE))
+        {
+            const bool do_rfi = (props & QR_PROP_REFRACT) || (props & QR_PROP_FRESNEL);
+            bool tir = false;
+            V3 nd = r.dir;
+            if (do_rfi)
+            {
+                x1 = r.dir.x; x7 = x1 * x1; x0 = x7;
+                x2 = r.dir.y; x7 = x2 * x2; x0 = x0 + x7;
+                x3 = r.dir.z; x7 = x3 * x3; x0 = x0 + x7;
+                x7 = rsq(x0);
+                x1 = x1 * x7; x2 = x2 * x7; x3 = x3 * x7;
+                x7 = x1 * nrm.x; x0 = x7;
+                x7 = x2 * nrm.y; x0 = x0 + x7;
+                x7 = x3 * nrm.z; x0 = x0 + x7;
+                x4 = x0;
+                x6 = mt->c_rfr;
+                x0 = x0 * x6;
+                x7 = x0 * x0;
+                x7 = x7 + 1.0f;
+                x7 = x7 - mt->rfr_2;
+                if (props & QR_PROP_FRESNEL)
+                {
+                    m_trn = cle(0.0f, x7);
+                    if (!m_trn)
+                    {
+                        c_trn = 0.0f;
+                        c_rfl = m_rfl_c + m_trn_c;
+                        tir = true;
+                    }
+                }
+                if (!tir)
+                {
+                    x7 = __builtin_sqrtf(x7);
+                    x0 = x0 + x7;
+                    if (props & QR_PROP_REFRACT)
+                    {
+                        x5 = nrm.x * x0; x1 = x1 * x6; nd.x = x1 - x5;
+                        x5 = nrm.y * x0; x2 = x2 * x6; nd.y = x2 - x5;
+                        x5 = nrm.z * x0; x3 = x3 * x6; nd.z = x3 - x5;
+                    }
+                }
+            }
+            if (!tir)
+            {
+                if (props & QR_PROP_FRESNEL)
+                {
+                    x1 = x4;
+                    x2 = x1; x2 = x2 * x6; x2 = x2 - x7;
+                    x7 = x7 * x6;
+                    x3 = x1;
+                    x1 = x1 + x7;
+                    x3 = x3 - x7;
+                    x0 = x0 / x2;
+                    x1 = x1 / x3;
+                    x0 = x0 * x0; x1 = x1 * x1;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                    const float f = x0 * m_trn_c;   /* m_trn is true here */
+                    c_trn = m_trn_c - f;
+                    c_rfl = m_rfl_c + f;
+                }
+                o.want_tr = m_trn;
+                o.tdir = nd;
+                o.lst_tr = sd->lst[(1 - side) * 2 + 1];
+            }
+        }
+
+        /* TR_mix factor 3564-3573 */
+        x0 = 1.0f - m_trn_c;
+        x0 = x0 - m_rfl_c;
+        x0 = cle(0.0f, x0) ? x0 : 0.0f;
+        o.x0 = x0;
+
+        /* reflections 3604-3815 */
+        if ((props & QR_PROP_REFLECT) ||
+            (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL)))
+        {
+            x1 = r.dir.x; x4 = nrm.x; x7 = x1 * x1; x0 = x7;
+            x2 = r.dir.y; x5 = nrm.y; x7 = x2 * x2; x0 = x0 + x7;
+            x3 = r.dir.z; x6 = nrm.z; x7 = x3 * x3; x0 = x0 + x7;
+            x7 = rsq(x0);
+            x1 = x1 * x7; x2 = x2 * x7; x3 = x3 * x7;
+            x7 = x1 * x4; x0 = x7;
+            x7 = x2 * x5; x0 = x0 + x7;
+            x7 = x3 * x6; x0 = x0 + x7;
+            x4 = x4 * x0; x1 = x1 - x4; x1 = x1 - x4; o.rdir.x = x1;
+            x5 = x5 * x0; x2 = x2 - x5; x2 = x2 - x5; o.rdir.y = x2;
+            x6 = x6 * x0; x3 = x3 - x6; x3 = x3 - x6; o.rdir.z = x3;
+
+            if ((props & QR_PROP_FRESNEL) && (props & QR_PROP_OPAQUE))
+            {
+                if (props & QR_PROP_METAL)
+                {
+                    x6 = mt->c_rcp;
+                    x4 = x0; x4 = x4 * x6; x4 = x4 + x4;
+                    x0 = x0 * x0;
+                    x6 = x6 * x6;
+                    x6 = x6 + mt->ext_2;
+                    x1 = x0; x1 = x1 * x6;
+                    x0 = x0 + x6;
+                    x1 = x1 + 1.0f;
+                    x2 = x0; x3 = x1;
+                    x0 = x0 + x4; x1 = x1 + x4;
+                    x2 = x2 - x4; x3 = x3 - x4;
+                    x0 = x0 / x2; x1 = x1 / x3;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                }
+                else
+                {
+                    x4 = x0;
+                    x6 = mt->c_rfr;
+                    x0 = x0 * x6;
+                    x7 = x0 * x0;
+                    x7 = x7 + 1.0f;
+                    x7 = x7 - mt->rfr_2;
+                    x7 = __builtin_sqrtf(x7);
+                    x0 = x0 + x7;
+                    x1 = x4;
+                    x2 = x1; x2 = x2 * x6; x2 = x2 - x7;
+                    x7 = x7 * x6;
+                    x3 = x1;
+                    x1 = x1 + x7;
+                    x3 = x3 - x7;
+                    x0 = x0 / x2; x1 = x1 / x3;
+                    x0 = x0 * x0; x1 = x1 * x1;
+                    x0 = x0 + x1;
+                    x0 = x0 * -0.5f;
+                    x0 = fabs_bits(x0);
+                }
+                x0 = x0 - 1.0f;
+                x0 = x0 * m_rfl_c;
+                c_rfl = m_rfl_c + x0;
+            }
+            o.want_rf = true;
+            o.lst_rf = sd->lst[side * 2 + 1];
+        }
+        o.c_trn = c_trn;
+        o.c_rfl = c_rfl;
+    }
+}
+
+#endif /* QR_SHADE_HPP */
