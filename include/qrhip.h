@@ -118,6 +118,24 @@ int qr_scene_upload(const void *blob, uint64_t size, int device, qr_device_scene
 #define QR_UPLOAD_REBIN_TILES 1u
 int qr_scene_upload_ex(const void *blob, uint64_t size, int device, uint32_t flags, qr_device_scene **out);
 int qr_scene_destroy(qr_device_scene *scn);
+
+/*
+ * Host-only half of an upload: validate the snapshot and compile it into the device image the kernel walks
+ * (contiguous list programs, clipper programs, light lists, wave schedule; csrc/qr_program.h), verify every
+ * offset in the image, and report its size.  Needs no GPU: the same code runs inside qr_scene_upload, so a
+ * snapshot this call accepts cannot make the kernel read outside the image.
+ */
+typedef struct qr_program_info
+{
+    uint64_t bytes;             /* size of the device image                                   */
+    uint32_t n_lists;           /* distinct surface lists compiled                            */
+    uint32_t n_cells;           /* cells in them (END cells not counted)                      */
+    uint32_t n_dropped;         /* snapshot cells that needed no device cell (markers)        */
+    uint32_t n_clip_cells;      /* cells of clipper programs                                  */
+    uint32_t n_sched;           /* wave-schedule entries (= waves of a whole-frame launch)    */
+    uint32_t reserved[3];
+} qr_program_info;
+int qr_program_stats(const void *blob, uint64_t size, qr_program_info *info);
 int qr_scene_get_info(const qr_device_scene *scn, qr_scene_info *info);
 
 /* Override recursion depth (s_inf->depth, tracer.h:173) of an uploaded scene. */

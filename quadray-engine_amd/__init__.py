@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR
 # every symbol include/qrhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
-    "qr_scene_upload", "qr_scene_upload_ex", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
+    "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
     "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
@@ -38,6 +38,12 @@ class SceneInfo(ctypes.Structure):
                 ("n_lgt", ctypes.c_int32), ("n_elm", ctypes.c_int32), ("n_tiles", ctypes.c_int32),
                 ("n_texels", ctypes.c_int32), ("tile_w", ctypes.c_int32), ("tile_h", ctypes.c_int32),
                 ("device_bytes", ctypes.c_uint64)]
+
+
+class ProgramInfo(ctypes.Structure):
+    _fields_ = [("bytes", ctypes.c_uint64), ("n_lists", ctypes.c_uint32), ("n_cells", ctypes.c_uint32),
+                ("n_dropped", ctypes.c_uint32), ("n_clip_cells", ctypes.c_uint32), ("n_sched", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 3)]
 
 
 class RayCounts(ctypes.Structure):
@@ -77,6 +83,7 @@ def lib():
     L.qr_scene_upload.argtypes = [vp, cu64, ci, ctypes.POINTER(vp)]
     L.qr_scene_upload_ex.argtypes = [vp, cu64, ci, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.qr_scene_destroy.argtypes = [vp]
+    L.qr_program_stats.argtypes = [vp, cu64, ctypes.POINTER(ProgramInfo)]
     L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
     L.qr_scene_set_depth.argtypes = [vp, ci]
     L.qr_scene_set_rows.argtypes = [vp, ci, ci, ci, ci]
@@ -101,6 +108,14 @@ def read_snapshot(path):
     with open(path, "rb") as f:
         raw = f.read()
     return gzip.decompress(raw) if path.endswith(".gz") else raw
+
+
+def program_stats(blob):
+    """Validate + compile a snapshot on the host (no GPU): the device image's size and cell counts."""
+    info = ProgramInfo()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    _check(lib().qr_program_stats(buf, len(blob), ctypes.byref(info)))
+    return info
 
 
 class Scene:

@@ -14,7 +14,6 @@
  * time, never correctness; the radius is inflated so that fp32 rounding in the device test and
  * in the reference's hit points cannot turn a real hit into a cull.
  */
-struct BSphere { float c[3]; float r; };
 struct BBox { bool valid; double p[8][3]; };     /* world-space corners of the (oriented) bounding box */
 
 static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)

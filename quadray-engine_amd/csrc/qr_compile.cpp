@@ -1,0 +1,672 @@
+/*
+ * qr_compile.cpp - host side: snapshot (include/qr_scene.h) -> the compiled device image of qr_program.h.
+ *
+ *   qr_snapshot_validate   every index, list and tag the compiler follows (a malformed snapshot is rejected
+ *                          here and can never become an out-of-bounds device access)
+ *   qr_program_build       per-surface records, list programs, clipper programs, light lists, wave schedule
+ *   qr_program_verify      walks the finished image once more and checks every offset the kernel will follow
+ *
+ * What the list compiler resolves statically is the reference's per-ray walk state that depends only on the
+ * list position: `ctx_LOCAL(OBJ)` (tracer.cpp:1385-1417: are we inside a trnode whose transform is cached?),
+ * the end of bounding-volume arrays (AR_skp 3955-4054), and, for clipper lists, the same caching of the clipper
+ * trnode (1931-2151).  Pure host code: no HIP here, so the CPU test-suite exercises it on every fixture.
+ */
+#include "qr_internal.h"
+#include "qr_program.h"
+#include "qr_bounds.hpp"
+
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+
+namespace {
+
+inline bool is_real(const qr_surface &s) { return s.srf_t[3] >= 0 && s.srf_t[3] < QR_TAG_SURFACE_MAX; }
+
+struct Fail { int rc; std::string msg; };
+
+} // namespace
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* validation                                                                                              */
+/* ------------------------------------------------------------------------------------------------------- */
+
+int qr_snapshot_validate(const qr_scene_view &v, std::string &err)
+{
+    const qr_frame &fr = *v.frame;
+    auto bad = [&](int rc, const char *m) { err = m; return rc; };
+    if (fr.fsaa < 0 || fr.fsaa > 2) return bad(QR_ERR_UNSUP, "unsupported fsaa");
+    if (fr.frm_w <= 0 || fr.frm_h <= 0 || fr.tile_w <= 0 || fr.tile_h <= 0) return bad(QR_ERR_ARG, "bad frame parameters");
+    if (fr.depth < 0) return bad(QR_ERR_ARG, "negative recursion depth");
+    if (fr.tls_row <= 0 || fr.tls_col <= 0) return bad(QR_ERR_ARG, "tile grid must be positive");
+    if ((int64_t)fr.tls_row * fr.tile_w < fr.frm_w || (int64_t)fr.tls_col * fr.tile_h < fr.frm_h)
+        return bad(QR_ERR_ARG, "tile grid does not cover the frame");
+    if (fr.thnum < 0 || fr.index < 0 || (fr.thnum > 0 && fr.index >= fr.thnum) || (fr.thnum == 0 && fr.index != 0))
+        return bad(QR_ERR_ARG, "bad index/thnum");
+
+    const int n_srf = (int)v.hdr->n_srf, n_mat = (int)v.hdr->n_mat, n_lgt = (int)v.hdr->n_lgt;
+    const int n_elm = (int)v.hdr->n_elm, n_tex = (int)v.hdr->n_texels;
+    auto ok_elm = [&](int i) { return i == QR_NULL || (i >= 0 && i < n_elm); };
+    auto ok_srf = [&](int i) { return i >= 0 && i < n_srf; };
+    for (int i = 0; i < n_elm; i++)
+        if (!ok_elm(v.elm[i].next)) return bad(QR_ERR_ARG, "element next out of range");
+    for (uint32_t i = 0; i < v.hdr->n_tiles; i++)
+        if (!ok_elm(v.tiles[i])) return bad(QR_ERR_ARG, "tile head out of range");
+    if (!ok_elm(fr.clist)) return bad(QR_ERR_ARG, "clist out of range");
+    for (int i = 0; i < n_mat; i++)
+    {
+        const qr_material &m = v.mat[i];
+        const uint64_t n = (uint64_t)(m.xmask + 1) * (m.ymask + 1);
+        if (m.tex < 0 || (uint64_t)m.tex + n > (uint64_t)n_tex) return bad(QR_ERR_ARG, "texture out of range");
+        if (m.t_map[0] < 0 || m.t_map[0] > 1 || m.t_map[1] < 0 || m.t_map[1] > 1) return bad(QR_ERR_ARG, "bad t_map");
+        if ((m.xmask & (m.xmask + 1)) != 0 || (m.ymask & (m.ymask + 1)) != 0) return bad(QR_ERR_ARG, "texture size not a power of two");
+        if (((uint64_t)m.ymask << (m.yshft & 31)) + m.xmask >= n) return bad(QR_ERR_ARG, "texture addressing exceeds texture");
+    }
+    /* every list is walked once per kind with a step bound (cycle check) */
+    std::vector<uint8_t> checked((size_t)n_elm + 1, 0);
+    auto check_list = [&](int head, int kind) -> const char * {
+        /* kind 0 surfaces, 1 clippers, 2 lights */
+        if (head == QR_NULL) return nullptr;
+        if (checked[head] & (1u << kind)) return nullptr;
+        checked[head] |= (uint8_t)(1u << kind);
+        int cnt = 0;
+        for (int e = head; e != QR_NULL; e = v.elm[e].next)
+        {
+            if (++cnt > n_elm) return "cyclic list";
+            const qr_elem &el = v.elm[e];
+            if (kind == 2)
+            {
+                if (el.simd < 0 || el.simd >= n_lgt) return "light index out of range";
+                if (!ok_elm(el.data)) return "shadow list out of range";
+            }
+            else if (kind == 0)
+            {
+                if (!ok_srf(el.simd)) return "surface index out of range";
+                if (el.data != QR_NULL && !ok_elm(el.data)) return "array last element out of range";
+            }
+            else if (el.simd != QR_NULL)
+            {
+                if (!ok_srf(el.simd)) return "clipper index out of range";
+                if (v.srf[el.simd].srf_t[3] < 0 && !ok_elm(el.data)) return "clip trnode last out of range";
+            }
+        }
+        return nullptr;
+    };
+    for (uint32_t i = 0; i < v.hdr->n_tiles; i++)
+        if (const char *m = check_list(v.tiles[i], 0)) return bad(QR_ERR_ARG, m);
+    if (const char *m = check_list(fr.clist, 0)) return bad(QR_ERR_ARG, m);
+    for (int i = 0; i < n_srf; i++)
+    {
+        const qr_surface &s = v.srf[i];
+        if (s.trnode != QR_NULL && !ok_srf(s.trnode)) return bad(QR_ERR_ARG, "trnode out of range");
+        const bool real = is_real(s);
+        if (s.has_trm != 0 && s.trnode == QR_NULL && real) return bad(QR_ERR_ARG, "transformed surface without trnode");
+        for (int k = 0; k < 3; k++)
+            if (((s.axes >> (2 * k)) & 3) > 2) return bad(QR_ERR_ARG, "bad axis map");
+        if ((s.conic & ~3) || (s.has_trm & ~3) || (s.srf_t[0] & ~3) || (s.srf_t[1] & ~3) || (s.srf_t[2] & ~3))
+            return bad(QR_ERR_ARG, "surface tag fields out of range");
+        if (!real) continue;
+        if (s.smask != 0x80000000u) return bad(QR_ERR_ARG, "surface smask is not the fp32 sign bit");
+        if ((s.shift != 0) != (s.has_trm != 0))
+            return bad(QR_ERR_UNSUP, "surface with trnode shift but no transform flags (or the reverse)");
+        for (int k = 0; k < 2; k++)
+            if (s.mat[k] < 0 || s.mat[k] >= n_mat) return bad(QR_ERR_ARG, "material index out of range");
+        if (!ok_elm(s.clip) || !ok_elm(s.lst[0]) || !ok_elm(s.lst[1]) || !ok_elm(s.lst[2]) || !ok_elm(s.lst[3]))
+            return bad(QR_ERR_ARG, "surface list head out of range");
+        if (const char *m = check_list(s.clip, 1)) return bad(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[0], 2)) return bad(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[2], 2)) return bad(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[1], 0)) return bad(QR_ERR_ARG, m);
+        if (const char *m = check_list(s.lst[3], 0)) return bad(QR_ERR_ARG, m);
+        for (int side = 0; side < 2; side++)
+            for (int e = s.lst[side * 2]; e != QR_NULL; e = v.elm[e].next)
+                if (const char *m = check_list(v.elm[e].data, 0)) return bad(QR_ERR_ARG, m);
+    }
+    return QR_OK;
+}
+
+void qr_bound_spheres(const qr_scene_view &v, std::vector<BSphere> &out)
+{
+    const int n = (int)v.hdr->n_srf;
+    out.resize((size_t)n + 1);
+    for (int i = 0; i < n; i++)
+    {
+        out[i] = bound_sphere(v, i);
+    }
+    out[n].c[0] = out[n].c[1] = out[n].c[2] = 0.0f; out[n].r = __builtin_inff();
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* the compiler                                                                                            */
+/* ------------------------------------------------------------------------------------------------------- */
+
+namespace {
+
+struct Builder
+{
+    const qr_scene_view &v;
+    const std::vector<qr_elem> &E;          /* cells: the snapshot's, or the binning pass's                 */
+    const std::vector<BSphere> &bs;
+    const int cull_mode;
+    std::vector<uint8_t> &blob;
+    int n_srf, n_elm;
+    uint32_t o_srf = 0, o_shd = 0, o_mat = 0, o_lgt = 0, o_tex = 0;
+
+    std::vector<uint32_t> list_off;         /* surface list head -> byte offset of its program (0 unseen)   */
+    std::vector<uint32_t> light_off;        /* light list head  -> byte offset                               */
+    struct ClipKey { int head, trnode, cdef; uint32_t off; };
+    std::vector<ClipKey> clip_memo;
+    std::vector<int> chain_pos, chain_stamp; int stamp = 0;
+    QrProgramStats st = {};
+
+    Builder(const qr_scene_view &v_, const std::vector<qr_elem> &E_, const std::vector<BSphere> &bs_, int cm, std::vector<uint8_t> &b)
+        : v(v_), E(E_), bs(bs_), cull_mode(cm), blob(b), n_srf((int)v_.hdr->n_srf), n_elm((int)E_.size())
+    {
+        list_off.assign((size_t)n_elm + 1, 0); light_off.assign((size_t)n_elm + 1, 0);
+        chain_pos.assign((size_t)n_elm + 1, 0); chain_stamp.assign((size_t)n_elm + 1, -1);
+    }
+
+    uint32_t alloc(size_t bytes, size_t align)
+    {
+        size_t o = (blob.size() + align - 1) & ~(align - 1);
+        if (o + bytes > 0xFFFFFFF0ull) throw Fail{QR_ERR_NOMEM, "compiled scene exceeds 4 GiB"};
+        blob.resize(o + bytes, 0);
+        return (uint32_t)o;
+    }
+    template <typename T> T *at(uint32_t off) { return (T *)(blob.data() + off); }
+    uint32_t srf_off(int si) const { return o_srf + (uint32_t)si * (uint32_t)sizeof(DSurf); }
+
+    /* ---- surface lists ---- */
+    uint32_t compile_list(int head)
+    {
+        if (head == QR_NULL) return 0;
+        if (list_off[head]) return list_off[head];
+        struct Tmp { int e; uint32_t op; int si; int last; bool emit; };
+        std::vector<Tmp> ch;
+        stamp++;
+        for (int e = head; e != QR_NULL; e = E[e].next)
+        {
+            chain_stamp[e] = stamp; chain_pos[e] = (int)ch.size();
+            ch.push_back(Tmp{e, 0, E[e].simd, QR_NULL, true});
+        }
+        const int n = (int)ch.size();
+        std::vector<int> lo_after((size_t)n, QR_NULL), lo_self((size_t)n, QR_NULL);
+        int local_obj = QR_NULL;
+        for (int i = 0; i < n; i++)
+        {
+            Tmp &t = ch[i];
+            const qr_elem &el = E[t.e];
+            const qr_surface &s = v.srf[el.simd];
+            const bool arr = s.srf_t[3] < 0, real = is_real(s);
+            const bool bv = (el.kind & 3) == 1;
+            uint32_t mode, type;
+            bool trnode_cell = false;
+            if (!arr && local_obj != QR_NULL)
+            {
+                mode = QR_OPM_CACHED;
+                if (t.e == local_obj) local_obj = QR_NULL;
+            }
+            else if (s.has_trm == 0) mode = QR_OPM_NONE;
+            else if (arr) { mode = QR_OPM_NONE; trnode_cell = true; local_obj = el.data; }
+            else mode = QR_OPM_OWN;
+            lo_self[i] = local_obj;
+            const int solver = real ? s.srf_t[0] : 0;
+            if (trnode_cell)
+            {
+                if (bv) throw Fail{QR_ERR_UNSUP, "bounding volume on a transformed array element"};
+                if (el.data == QR_NULL || chain_stamp[el.data] != stamp || chain_pos[el.data] < i)
+                    throw Fail{QR_ERR_ARG, "trnode's last element is not behind it in its list"};
+                type = QR_OP_TRNODE; t.last = chain_pos[el.data];
+            }
+            else if (bv)
+            {
+                if (el.data == QR_NULL || chain_stamp[el.data] != stamp || chain_pos[el.data] < i)
+                    throw Fail{QR_ERR_ARG, "array's last element is not behind it in its list"};
+                type = QR_OP_BV; t.last = chain_pos[el.data];
+            }
+            else if (solver == 1) type = QR_OP_PLANE;
+            else if (solver == 2) type = QR_OP_QUADRIC;
+            else if (solver == 3) type = QR_OP_TWOPLANE;
+            else { type = QR_OP_END; t.emit = false; }    /* marker: touches only state nobody reads */
+            if (t.emit && type != QR_OP_TRNODE && ((s.shift != 0) != (mode != QR_OPM_NONE)))
+                throw Fail{QR_ERR_UNSUP, "surface reads the trnode-space diff outside a trnode (or the reverse)"};
+            uint32_t op = type | (mode << QR_OPM_SHIFT);
+            if (s.has_trm != 1) op |= QR_OPF_FULLM;
+            if (type == QR_OP_PLANE || type == QR_OP_QUADRIC || type == QR_OP_TWOPLANE)
+            {
+                op |= ((s.axes >> 4) & 3u) << 8;
+                if ((s.axes >> 10) & 1u) op |= QR_OPF_SGNK;
+                op |= ((s.axes >> 0) & 3u) << 11;
+                auto no_shadow = [](int p) { return (p & QR_PROP_LIGHT) || ((p & QR_PROP_TRANSP) && !(p & QR_PROP_REFRACT)); };
+                const bool n0 = no_shadow(s.props[0]), n1 = no_shadow(s.props[1]);
+                op |= (n0 && n1 ? 1u : (!n0 && !n1 ? 0u : 2u)) << 13;
+                if (s.clip != QR_NULL) op |= QR_OPF_CLIP;
+                if (s.conic != 0) op |= QR_OPF_CONIC;
+                const bool open_shape = s.srf_t[0] == 1 || !(s.sci[0] > 0.0f && s.sci[1] > 0.0f && s.sci[2] > 0.0f);
+                const bool want = cull_mode >= 3 || (cull_mode == 2 && open_shape) || (cull_mode == 1 && s.srf_t[0] == 1);
+                if (want && bs[el.simd].r < 1e30f) op |= QR_OPF_CULL;
+            }
+            t.op = op;
+            lo_after[i] = local_obj;
+        }
+        /* static state must not depend on whether a ray walked through an array or skipped it (AR_skp:
+         * e = last; if (e == local_obj) local_obj = NULL), and arrays must nest */
+        {
+            std::vector<int> open;
+            for (int i = 0; i < n; i++)
+            {
+                while (!open.empty() && open.back() < i) open.pop_back();
+                if (QR_OP_TYPE(ch[i].op) != QR_OP_BV || !ch[i].emit) continue;
+                const int j = ch[i].last;
+                int lo = lo_self[i];
+                if (lo == ch[j].e) lo = QR_NULL;
+                if (lo != lo_after[j]) throw Fail{QR_ERR_UNSUP, "a trnode's range crosses the end of a bounding-volume array"};
+                if (!open.empty() && j > open.back()) throw Fail{QR_ERR_UNSUP, "bounding-volume arrays are not nested"};
+                open.push_back(j);
+            }
+        }
+        /* emit */
+        std::vector<int> emit_idx((size_t)n + 1, 0);
+        int ne = 0;
+        for (int i = 0; i < n; i++) { emit_idx[i] = ne; if (ch[i].emit) ne++; }
+        emit_idx[n] = ne;
+        const uint32_t off = alloc((size_t)(ne + 1) * sizeof(CCell), 32);
+        list_off[head] = off;
+        for (int i = 0; i < n; i++)
+        {
+            if (!ch[i].emit) continue;
+            CCell c;
+            memset(&c, 0, sizeof(c));
+            c.op = ch[i].op; c.si = ch[i].si; c.srf = srf_off(ch[i].si);
+            if (ch[i].last != QR_NULL) c.end = off + (uint32_t)emit_idx[ch[i].last + 1] * (uint32_t)sizeof(CCell);
+            c.r = __builtin_inff();
+            if (c.op & QR_OPF_CULL) { const BSphere &b = bs[ch[i].si]; c.cx = b.c[0]; c.cy = b.c[1]; c.cz = b.c[2]; c.r = b.r; }
+            *at<CCell>(off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell)) = c;
+        }
+        /* END cell: already zero */
+        st.n_lists++; st.n_cells += (uint32_t)ne; st.n_dropped += (uint32_t)(n - ne);
+        /* lists reachable from this one are compiled by their owners (surface records) */
+        return off;
+    }
+
+    /* ---- clipper programs ---- */
+    uint32_t compile_clip(int owner)
+    {
+        const qr_surface &s = v.srf[owner];
+        if (s.clip == QR_NULL) return 0;
+        const int cdef = s.c_def != 0 ? 1 : 0;
+        for (const ClipKey &k : clip_memo)
+            if (k.head == s.clip && k.trnode == s.trnode && k.cdef == cdef) return k.off;
+        std::vector<CClip> prog;
+        int redx = QR_NULL;
+        for (int e = s.clip; e != QR_NULL; e = E[e].next)
+        {
+            const qr_elem &el = E[e];
+            CClip c = {0, 0, 0, 0};
+            if (el.simd == QR_NULL)
+            {
+                c.op = el.data > 0 ? QR_CL_LEAVE : (QR_CL_ENTER | (cdef ? QR_CLF_CDEF : 0u));
+                prog.push_back(c);
+                continue;
+            }
+            const qr_surface &k = v.srf[el.simd];
+            const bool karr = k.srf_t[3] < 0;
+            c.srf = srf_off(el.simd);
+            if (k.has_trm != 1) c.op |= QR_CLF_FULLM;
+            uint32_t mode;
+            if (!karr)
+            {
+                if (redx != QR_NULL) { mode = QR_OPM_CACHED; if (e == redx) redx = QR_NULL; }
+                else mode = k.has_trm != 0 ? QR_OPM_OWN : QR_OPM_NONE;
+            }
+            else if (el.simd == s.trnode)
+            {
+                if (s.has_trm == 0) throw Fail{QR_ERR_UNSUP, "clipper trnode shared with an untransformed surface"};
+                c.op |= QR_CL_TRSAME; redx = el.data; prog.push_back(c); continue;
+            }
+            else
+            {
+                if (k.has_trm == 0)
+                {
+                    /* array without transform: outside a cached trnode it writes only state nobody reads */
+                    if (redx != QR_NULL) throw Fail{QR_ERR_UNSUP, "untransformed array inside a clipper trnode"};
+                    continue;
+                }
+                c.op |= QR_CL_TRNODE; redx = el.data; prog.push_back(c); continue;
+            }
+            const int ckind = k.srf_t[2];
+            if (ckind == 0) continue;                   /* no clip function: no effect */
+            if ((k.shift != 0) != (mode != QR_OPM_NONE))
+                throw Fail{QR_ERR_UNSUP, "clipper reads the trnode-space hit outside a trnode (or the reverse)"};
+            c.op |= (uint32_t)ckind | (mode << QR_CLM_SHIFT);
+            if (el.data < 0) c.op |= QR_CLF_INNER;
+            c.op |= ((k.axes >> 4) & 3u) << 8;
+            if ((k.axes >> 10) & 1u) c.op |= QR_CLF_SGNK;
+            prog.push_back(c);
+        }
+        CClip endc = {QR_CL_END, 0, 0, 0};
+        prog.push_back(endc);
+        const uint32_t off = alloc(prog.size() * sizeof(CClip), 16);
+        memcpy(at<CClip>(off), prog.data(), prog.size() * sizeof(CClip));
+        clip_memo.push_back(ClipKey{s.clip, s.trnode, cdef, off});
+        st.n_clip_cells += (uint32_t)prog.size() - 1;
+        return off;
+    }
+
+    /* ---- light lists ---- */
+    uint32_t compile_lights(int head)
+    {
+        if (head == QR_NULL) return 0;
+        if (light_off[head]) return light_off[head];
+        std::vector<CLight> ls;
+        for (int e = head; e != QR_NULL; e = E[e].next)
+        {
+            CLight l;
+            l.lgt = o_lgt + (uint32_t)E[e].simd * (uint32_t)sizeof(qr_light);
+            l.shadow = compile_list(E[e].data);
+            ls.push_back(l);
+        }
+        ls.back().lgt |= QR_CLIGHT_LAST;
+        const uint32_t off = alloc(ls.size() * sizeof(CLight), 8);
+        memcpy(at<CLight>(off), ls.data(), ls.size() * sizeof(CLight));
+        light_off[head] = off;
+        return off;
+    }
+};
+
+} // namespace
+
+int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
+                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err)
+{
+    const int n_srf = (int)v.hdr->n_srf, n_mat = (int)v.hdr->n_mat, n_lgt = (int)v.hdr->n_lgt, n_tex = (int)v.hdr->n_texels;
+    const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
+    const int cull_mode = cm ? atoi(cm) : 3;
+    out.blob.clear();
+    out.frm = frm;
+    if ((size_t)frm.tls_row * frm.tls_col != T.size()) { err = "tile grid does not match the tile array"; return QR_ERR_ARG; }
+    try
+    {
+        Builder b(v, E, bs, cull_mode, out.blob);
+        /* fixed sections; index n_* is a zero record so that masked-off lanes may read it */
+        b.alloc(sizeof(DevHeader), 256);
+        b.o_srf = b.alloc((size_t)(n_srf + 1) * sizeof(DSurf), 128);
+        if (b.o_srf != QR_OFF_SRF) throw Fail{QR_ERR_ARG, "layout: DSurf array is not at QR_OFF_SRF"};
+        b.o_shd = b.alloc((size_t)(n_srf + 1) * sizeof(DShade), 32);
+        b.o_mat = b.alloc((size_t)(n_mat + 1) * sizeof(qr_material), 128);
+        b.o_lgt = b.alloc((size_t)(n_lgt + 1) * sizeof(qr_light), 64);
+        b.o_tex = b.alloc((size_t)(n_tex + 1) * 4, 16);
+        const uint32_t o_til = b.alloc((T.size() + 1) * 4, 16);
+
+        /* wave schedule geometry */
+        const int fw = frm.fsaa == 2 ? 4 : 8, fh = frm.fsaa == 0 ? 8 : 4;
+        const int nbx = (frm.frm_w + fw - 1) / fw, nby = (frm.frm_h + fh - 1) / fh;
+        if (nbx > 0x3FFF || nby > 0x3FFF) throw Fail{QR_ERR_ARG, "frame too large"};
+        const size_t n_sched = (size_t)nbx * nby;
+        const uint32_t o_ord = b.alloc(n_sched * 8 + 16, 16);
+
+        /* materials, lights, texels */
+        memcpy(b.at<qr_material>(b.o_mat), v.mat, (size_t)n_mat * sizeof(qr_material));
+        for (int i = 0; i < n_mat; i++) b.at<qr_material>(b.o_mat)[i].tex = (int32_t)(b.o_tex + (uint32_t)v.mat[i].tex * 4u);
+        b.at<qr_material>(b.o_mat)[n_mat].tex = (int32_t)b.o_tex;
+        b.at<qr_material>(b.o_mat)[n_mat].clamp = 1.0f;
+        memcpy(b.at<qr_light>(b.o_lgt), v.lgt, (size_t)n_lgt * sizeof(qr_light));
+        memcpy(b.at<uint32_t>(b.o_tex), v.texels, (size_t)n_tex * 4);
+
+        /* tile lists */
+        std::vector<uint32_t> tile_off(T.size());
+        for (size_t i = 0; i < T.size(); i++) tile_off[i] = b.compile_list(T[i]);
+        memcpy(b.at<uint32_t>(o_til), tile_off.data(), tile_off.size() * 4);
+
+        /* per-surface records (filled after the lists they point to exist) */
+        for (int i = 0; i < n_srf; i++)
+        {
+            const qr_surface &q = v.srf[i];
+            const bool real = is_real(q);
+            DSurf d;
+            memset(&d, 0, sizeof(d));
+            for (int k = 0; k < 3; k++)
+            {
+                d.pos[k] = q.pos[k]; d.scj[k] = q.scj[k];
+                /* an axis without clipping gets an infinite bound: the kernel compares unconditionally */
+                d.min[k] = (q.minmax_t & (1u << k)) ? q.min[k] : -__builtin_inff();
+                d.max[k] = (q.minmax_t & (1u << (3 + k))) ? q.max[k] : __builtin_inff();
+                d.tci[k] = q.tci[k]; d.tcj[k] = q.tcj[k]; d.tck[k] = q.tck[k];
+            }
+            for (int k = 0; k < 4; k++) d.sci[k] = q.sci[k];
+            d.d_eps = q.d_eps; d.t_eps = q.t_eps;
+            d.trn = q.trnode != QR_NULL ? b.srf_off(q.trnode) : b.srf_off(n_srf);
+            d.props0 = q.props[0]; d.props1 = q.props[1];
+            uint32_t f = 0;
+            f |= q.minmax_t & 63u;
+            f |= ((uint32_t)q.conic & 3u) << 6;
+            f |= ((uint32_t)q.has_trm & 3u) << 8;
+            f |= (q.shift ? 1u : 0u) << 10;
+            f |= ((q.axes >> 0) & 3u) << 11; f |= ((q.axes >> 2) & 3u) << 13; f |= ((q.axes >> 4) & 3u) << 15;
+            f |= ((q.axes >> 8) & 7u) << 17;
+            f |= (real ? ((uint32_t)q.srf_t[0] & 3u) : 0u) << 20;
+            f |= ((uint32_t)q.srf_t[1] & 3u) << 22;
+            f |= ((uint32_t)q.srf_t[2] & 3u) << 24;
+            f |= (q.srf_t[3] < 0 ? 1u : 0u) << 26;
+            f |= (q.c_def != 0 ? 1u : 0u) << 28;
+            d.flags = f;
+            DShade h;
+            memset(&h, 0, sizeof(h));
+            h.srf = b.srf_off(i);
+            h.mat[0] = h.mat[1] = b.o_mat + (uint32_t)n_mat * (uint32_t)sizeof(qr_material);
+            if (real)
+            {
+                d.clip = b.compile_clip(i);
+                for (int k = 0; k < 2; k++)
+                {
+                    h.mat[k] = b.o_mat + (uint32_t)q.mat[k] * (uint32_t)sizeof(qr_material);
+                    h.lgt[k] = b.compile_lights(q.lst[k * 2]);
+                    h.lst[k] = b.compile_list(q.lst[k * 2 + 1]);
+                }
+            }
+            b.at<DSurf>(b.o_srf)[i] = d;
+            b.at<DShade>(b.o_shd)[i] = h;
+        }
+        b.at<DShade>(b.o_shd)[n_srf].srf = b.srf_off(n_srf);
+        b.at<DShade>(b.o_shd)[n_srf].mat[0] = b.at<DShade>(b.o_shd)[n_srf].mat[1] = b.o_mat + (uint32_t)n_mat * (uint32_t)sizeof(qr_material);
+        for (int k = 0; k < 3; k++) { b.at<DSurf>(b.o_srf)[n_srf].min[k] = -__builtin_inff(); b.at<DSurf>(b.o_srf)[n_srf].max[k] = __builtin_inff(); }
+        b.at<DSurf>(b.o_srf)[n_srf].trn = b.srf_off(n_srf);
+
+        /* wave schedule: one entry {footprint | heaviness << 30, tile-list offset} per wave footprint.
+         * heavy = the footprint's tile list holds a reflective or non-opaque surface: those waves can spawn
+         * recursion, are started first and get issue priority */
+        std::vector<uint8_t> tile_heavy(T.size(), 0);
+        for (size_t t = 0; t < T.size(); t++)
+            for (int e = T[t]; e != QR_NULL; e = E[e].next)
+            {
+                const qr_surface &q = v.srf[E[e].simd];
+                if (!is_real(q)) continue;
+                for (int k = 0; k < 2; k++)
+                {
+                    if (q.props[k] & QR_PROP_REFLECT) tile_heavy[t] |= 1;
+                    if (!(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] |= 2;
+                }
+            }
+        {
+            /* footprints are enumerated tile by tile (32x8 pixel groups) to keep neighbours together */
+            const int gx = 32 / fw, gy = 8 / fh;
+            const bool nest = frm.tile_w == 32 && frm.tile_h == 8;      /* group (tx, ty) IS tile (tx, ty) */
+            std::vector<uint32_t> &hv_ent = out.order, lt_ent;
+            hv_ent.clear();
+            hv_ent.reserve(n_sched * 2); lt_ent.reserve(n_sched * 2);
+            for (int ty = 0; ty * gy < nby; ty++)
+                for (int tx = 0; tx * gx < nbx; tx++)
+                {
+                    int g_hv = 0; uint32_t g_head = QR_SCHED_PER_LANE;
+                    if (nest && tx < frm.tls_row && ty < frm.tls_col)
+                    {
+                        const size_t t = (size_t)ty * frm.tls_row + tx;
+                        g_hv = tile_heavy[t]; g_head = tile_off[t];
+                    }
+                    for (int j = 0; j < gy; j++)
+                        for (int i = 0; i < gx; i++)
+                        {
+                            const int bx = tx * gx + i, by = ty * gy + j;
+                            if (bx >= nbx || by >= nby) continue;
+                            int hv = g_hv; uint32_t head = g_head;
+                            if (!nest)
+                            {
+                                const int x0 = bx * fw, y0 = by * fh;
+                                const int x1 = std::min(x0 + fw - 1, frm.frm_w - 1), y1 = std::min(y0 + fh - 1, frm.frm_h - 1);
+                                const int tlx = x0 / frm.tile_w, tly = y0 / frm.tile_h;
+                                hv = tile_heavy[(size_t)tly * frm.tls_row + tlx];
+                                head = QR_SCHED_PER_LANE;
+                                if (tlx == x1 / frm.tile_w && tly == y1 / frm.tile_h) head = tile_off[(size_t)tly * frm.tls_row + tlx];
+                                else for (int yy = tly; yy <= y1 / frm.tile_h; yy++) for (int xx = tlx; xx <= x1 / frm.tile_w; xx++) hv |= tile_heavy[(size_t)yy * frm.tls_row + xx];
+                            }
+                            const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14) | ((uint32_t)(hv & 3) << 30);
+                            std::vector<uint32_t> &dst = hv ? hv_ent : lt_ent;
+                            dst.push_back(ent); dst.push_back(head);
+                        }
+                }
+            hv_ent.insert(hv_ent.end(), lt_ent.begin(), lt_ent.end());
+        }
+        if (out.order.size() != n_sched * 2) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
+        memcpy(b.at<uint32_t>(o_ord), out.order.data(), out.order.size() * 4);
+
+        DevHeader &h = *b.at<DevHeader>(0);
+        h.fr = frm;
+        h.off_shade = b.o_shd; h.off_tiles = o_til; h.off_order = o_ord; h.n_blocks = (uint32_t)n_sched;
+        b.alloc(64, 64);                    /* tail padding: wide scalar loads of the last record stay inside */
+        out.off_order = o_ord; out.n_sched = (uint32_t)n_sched;
+        out.off_srf = b.o_srf; out.off_shade = b.o_shd; out.off_mat = b.o_mat; out.off_lgt = b.o_lgt; out.off_tex = b.o_tex; out.off_tiles = o_til;
+        out.n_srf = (uint32_t)n_srf; out.n_mat = (uint32_t)n_mat; out.n_lgt = (uint32_t)n_lgt; out.n_tex = (uint32_t)n_tex; out.n_tiles = (uint32_t)T.size();
+        out.off_lists = o_ord + (uint32_t)(n_sched * 8 + 16);
+        b.st.bytes = out.blob.size();
+        out.stats = b.st;
+    }
+    catch (const Fail &f) { err = f.msg; return f.rc; }
+    return qr_program_verify(out, err);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* verification of the finished image: every offset the kernel follows                                      */
+/* ------------------------------------------------------------------------------------------------------- */
+
+int qr_program_verify(const QrProgram &p, std::string &err)
+{
+    const std::vector<uint8_t> &b = p.blob;
+    const size_t N = b.size();
+    auto bad = [&](const char *m) { err = std::string("compiled scene fails verification: ") + m; return QR_ERR_ARG; };
+    if (N < sizeof(DevHeader) + 64) return bad("too small");
+    const size_t limit = N - 64;        /* records end before the tail padding */
+    auto in_arr = [&](uint32_t off, uint32_t base, uint32_t n, size_t sz) {
+        return off >= base && (off - base) % sz == 0 && (off - base) / sz <= n && (size_t)off + sz <= limit;
+    };
+    std::vector<uint8_t> seen_list(N / 32 + 1, 0);
+    /* a list program: cells inside the list area, END-terminated, array ends inside the run */
+    auto check_list = [&](uint32_t off) -> const char * {
+        if (off == 0) return nullptr;
+        if (off < p.off_lists || (off & 31) || (size_t)off + 32 > limit) return "list offset out of range";
+        if (seen_list[off / 32]) return nullptr;
+        seen_list[off / 32] = 1;
+        uint32_t o = off, end_cell = 0;
+        for (;; o += 32)
+        {
+            if ((size_t)o + 32 > limit) return "list runs off the image";
+            const CCell *c = (const CCell *)(b.data() + o);
+            if (QR_OP_TYPE(c->op) == QR_OP_END) { end_cell = o; break; }
+        }
+        for (o = off; o < end_cell; o += 32)
+        {
+            const CCell *c = (const CCell *)(b.data() + o);
+            const uint32_t t = QR_OP_TYPE(c->op);
+            if (t > QR_OP_TRNODE) return "bad opcode";
+            if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf))) return "cell surface offset out of range";
+            if (c->si < 0 || (uint32_t)c->si >= p.n_srf) return "cell surface index out of range";
+            if (t == QR_OP_BV && (c->end <= o || c->end > end_cell || (c->end & 31))) return "array end outside its list";
+            if (QR_OP_MODE(c->op) > QR_OPM_OWN) return "bad transform mode";
+            if (t == QR_OP_PLANE && QR_OP_AXK(c->op) > 2) return "bad plane axis";
+            if (t == QR_OP_TWOPLANE && (QR_OP_AXK(c->op) > 2 || QR_OP_AXI(c->op) > 2)) return "bad two-plane axes";
+        }
+        return nullptr;
+    };
+    const DevHeader *h = (const DevHeader *)b.data();
+    if (h->off_tiles != p.off_tiles || h->off_order != p.off_order || h->off_shade != p.off_shade) return bad("header offsets");
+    if ((size_t)p.off_tiles + (size_t)p.n_tiles * 4 > limit) return bad("tile array");
+    const uint32_t *tl = (const uint32_t *)(b.data() + p.off_tiles);
+    for (uint32_t i = 0; i < p.n_tiles; i++) if (const char *m = check_list(tl[i])) return bad(m);
+    if ((size_t)p.off_order + (size_t)p.n_sched * 8 > limit) return bad("schedule");
+    const uint32_t *ord = (const uint32_t *)(b.data() + p.off_order);
+    const int fw = p.frm.fsaa == 2 ? 4 : 8, fh = p.frm.fsaa == 0 ? 8 : 4;
+    for (uint32_t i = 0; i < p.n_sched; i++)
+    {
+        const uint32_t e = ord[2 * i], hd = ord[2 * i + 1];
+        if ((int)(e & 0x3FFFu) * fw >= p.frm.frm_w || (int)((e >> 14) & 0x3FFFu) * fh >= p.frm.frm_h) return bad("schedule footprint outside the frame");
+        if (hd != QR_SCHED_PER_LANE) if (const char *m = check_list(hd)) return bad(m);
+    }
+    for (uint32_t i = 0; i <= p.n_srf; i++)
+    {
+        const DSurf *d = (const DSurf *)(b.data() + p.off_srf) + i;
+        const DShade *s = (const DShade *)(b.data() + p.off_shade) + i;
+        if (!in_arr(d->trn, p.off_srf, p.n_srf, sizeof(DSurf))) return bad("trnode offset");
+        if (d->clip != 0)
+        {
+            if ((d->clip & 15) || d->clip < p.off_lists) return bad("clipper program offset");
+            for (uint32_t o = d->clip;; o += 16)
+            {
+                if ((size_t)o + 16 > limit) return bad("clipper program runs off the image");
+                const CClip *c = (const CClip *)(b.data() + o);
+                const uint32_t t = QR_CL_TYPE(c->op);
+                if (t == QR_CL_END) break;
+                if (t != QR_CL_ENTER && t != QR_CL_LEAVE && !in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf))) return bad("clipper surface offset");
+                if (t == QR_CL_PLANE && QR_CL_AXK(c->op) > 2) return bad("bad clipper axis");
+            }
+        }
+        for (int k = 0; k < 2; k++)
+        {
+            if (!in_arr(s->mat[k], p.off_mat, p.n_mat, sizeof(qr_material))) return bad("material offset");
+            if (const char *m = check_list(s->lst[k])) return bad(m);
+            if (s->lgt[k] != 0)
+            {
+                if ((s->lgt[k] & 7) || s->lgt[k] < p.off_lists) return bad("light list offset");
+                for (uint32_t o = s->lgt[k];; o += 8)
+                {
+                    if ((size_t)o + 8 > limit) return bad("light list runs off the image");
+                    const CLight *l = (const CLight *)(b.data() + o);
+                    const uint32_t lo = l->lgt & ~QR_CLIGHT_LAST;
+                    if (!in_arr(lo, p.off_lgt, p.n_lgt, sizeof(qr_light)) || lo == p.off_lgt + p.n_lgt * (uint32_t)sizeof(qr_light)) return bad("light offset");
+                    if (const char *m = check_list(l->shadow)) return bad(m);
+                    if (l->lgt & QR_CLIGHT_LAST) break;
+                }
+            }
+        }
+        if (s->srf != p.off_srf + i * (uint32_t)sizeof(DSurf)) return bad("shade record surface offset");
+    }
+    for (uint32_t i = 0; i <= p.n_mat; i++)
+    {
+        const qr_material *m = (const qr_material *)(b.data() + p.off_mat) + i;
+        const uint64_t n = (uint64_t)(m->xmask + 1) * (m->ymask + 1);
+        if ((uint32_t)m->tex < p.off_tex || ((uint32_t)m->tex & 3) || (uint64_t)(uint32_t)m->tex + n * 4 > (uint64_t)p.off_tex + ((uint64_t)p.n_tex + 1) * 4)
+            return bad("texture offset");
+    }
+    return QR_OK;
+}
+
+/* host-only entry point: validate + compile a snapshot without a device (used by the CPU test-suite) */
+extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info *info)
+{
+    if (blob == nullptr || info == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    qr_scene_view v;
+    const int rc0 = qr_scene_view_init(&v, blob, size);
+    if (rc0 != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc0) + ")");
+    std::string err;
+    int rc = qr_snapshot_validate(v, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    std::vector<BSphere> bs;
+    qr_bound_spheres(v, bs);
+    std::vector<qr_elem> E(v.elm, v.elm + v.hdr->n_elm);
+    std::vector<int32_t> T(v.tiles, v.tiles + v.hdr->n_tiles);
+    QrProgram p;
+    rc = qr_program_build(v, E, T, *v.frame, bs, p, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    memset(info, 0, sizeof(*info));
+    info->bytes = p.stats.bytes; info->n_lists = p.stats.n_lists; info->n_cells = p.stats.n_cells;
+    info->n_dropped = p.stats.n_dropped; info->n_clip_cells = p.stats.n_clip_cells; info->n_sched = p.n_sched;
+    return QR_OK;
+}

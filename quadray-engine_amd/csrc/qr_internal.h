@@ -1,6 +1,6 @@
 /*
  * qr_internal.h - declarations shared by the host-side translation units of
- * libqrhip (walker, snapshot I/O, C-ABI glue).  Not part of the public ABI.
+ * libqrhip (walker, snapshot I/O, scene compiler, C-ABI glue).  Not part of the public ABI.
  */
 #ifndef QR_INTERNAL_H
 #define QR_INTERNAL_H
@@ -19,5 +19,31 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi,
 /* thread-local error channel behind qr_last_error() (qr_capi_host.cpp) */
 void qr_set_error(const std::string &msg);
 int  qr_fail(int status, const std::string &msg);
+
+/* ---- scene compiler (qr_compile.cpp): snapshot -> device image of qr_program.h ---- */
+
+struct BSphere { float c[3]; float r; };    /* conservative world-space bounding sphere, r = +inf: unbounded */
+
+#define QR_SCHED_PER_LANE 0xFFFFFFFEu       /* schedule entry: the footprint straddles tiles, look the list up per pixel */
+
+struct QrProgramStats { uint64_t bytes; uint32_t n_lists, n_cells, n_dropped, n_clip_cells; };
+
+struct QrProgram
+{
+    std::vector<uint8_t> blob;      /* the device image, offsets relative to its first byte */
+    std::vector<uint32_t> order;    /* host copy of the whole-frame wave schedule, 2 words per wave */
+    qr_frame frm;
+    uint32_t off_order = 0, n_sched = 0;
+    uint32_t off_srf = 0, off_shade = 0, off_mat = 0, off_lgt = 0, off_tex = 0, off_tiles = 0, off_lists = 0;
+    uint32_t n_srf = 0, n_mat = 0, n_lgt = 0, n_tex = 0, n_tiles = 0;
+    QrProgramStats stats = {};
+};
+
+int  qr_snapshot_validate(const qr_scene_view &v, std::string &err);
+void qr_bound_spheres(const qr_scene_view &v, std::vector<BSphere> &out);
+/* E / T: list cells and tile heads (the snapshot's, or the ones the binning pass built); frm: frame record to use */
+int  qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
+                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err);
+int  qr_program_verify(const QrProgram &p, std::string &err);
 
 #endif /* QR_INTERNAL_H */

@@ -1,0 +1,138 @@
+/*
+ * qr_program.h - the COMPILED scene the render kernel walks (host + device definition).
+ *
+ * The snapshot (include/qr_scene.h) keeps the reference's linked lists: cells chained by `next`, the role of a
+ * cell (plain surface, bounding-volume array head, trnode with a cached transform, ...) decided while walking
+ * from tags and from per-ray state (`ctx_LOCAL(OBJ)`, tracer.cpp:1385-1417).  That state depends only on the
+ * position in the list, so the upload pass (qr_compile.cpp) resolves it ONCE per list:
+ *   - every distinct list becomes a contiguous run of 32-byte cells ending in an END cell (no `next` chasing);
+ *   - a cell's opcode word says what the walk has to do there: solver, which diff / ray the solver reads
+ *     (world, trnode-cached, own transform), whether a bounding-sphere cull applies, how shadows treat a hit;
+ *   - arrays carry the byte offset just behind their last cell: a ray that misses a bounding volume becomes
+ *     active again at that offset (one unsigned compare per cell decides who takes part), a wave no ray of which
+ *     enters it jumps there;
+ *   - cells the walk can neither hit nor needs for its state (markers without transform) are dropped.
+ * Everything in the device blob is addressed by BYTE OFFSETS from the blob's base, so the kernel keeps one
+ * 64-bit base in SGPRs instead of one pointer per array (the round-1 kernel spilled 88 SGPRs).
+ * Offset 0 is the header and never a valid list / record: 0 == "none".
+ */
+#ifndef QR_PROGRAM_H
+#define QR_PROGRAM_H
+
+#include <stdint.h>
+#include "qr_scene.h"
+
+/* ---- surface-list cells --------------------------------------------------------------------------------- */
+
+struct CCell                    /* 32 B, 32-byte aligned */
+{
+    uint32_t op;                /* QR_OP_* | flags below                                                */
+    uint32_t srf;               /* byte offset of the surface's DSurf                                    */
+    uint32_t end;               /* BV / TRNODE: byte offset just behind the array's last cell            */
+    int32_t  si;                /* surface index (hit ids, own-surface test)                             */
+    float    cx, cy, cz, r;     /* conservative world-space bounding sphere (QR_OPF_CULL cells)          */
+};
+
+#define QR_OP_END      0u       /* end of list                                                            */
+#define QR_OP_PLANE    1u       /* PL_ptr, tracer.cpp:4062-4136                                           */
+#define QR_OP_QUADRIC  2u       /* QD_ptr, 4378-4447                                                      */
+#define QR_OP_TWOPLANE 3u       /* TP_ptr, 4216-4277                                                      */
+#define QR_OP_BV       4u       /* AR_ptr bounding volume, 3955-4054                                      */
+#define QR_OP_TRNODE   5u       /* array element with a transform: fills the trnode cache, 1419-1556     */
+#define QR_OP_TYPE(op) ((op) & 7u)
+
+#define QR_OPF_CULL    (1u << 3)    /* bounding-sphere cull applies                                       */
+#define QR_OPM_SHIFT   4            /* bits 4-5: which diff / ray the cell reads                           */
+#define QR_OPM_NONE    0u           /*   world: diff = org - pos, ray = dir                                */
+#define QR_OPM_CACHED  1u           /*   inside a trnode: diff = cached - pos, ray = cached                */
+#define QR_OPM_OWN     2u           /*   own transform: diff = M (org - pos), ray = M dir                  */
+#define QR_OP_MODE(op) (((op) >> QR_OPM_SHIFT) & 3u)
+#define QR_OPF_FULLM   (1u << 6)    /* transform has rotation (a_map[L] != 1): full 3x3, else diagonal    */
+#define QR_OP_AXK(op)  (((op) >> 8) & 3u)      /* plane: axis k (two-plane: axis k too)                   */
+#define QR_OPF_SGNK    (1u << 10)               /* plane: sign of axis k                                   */
+#define QR_OP_AXI(op)  (((op) >> 11) & 3u)     /* two-plane: axis i                                       */
+#define QR_OP_SHAD(op) (((op) >> 13) & 3u)     /* CHECK_SHAD 549-589: 0 a hit occludes, 1 never, 2 by side */
+#define QR_OPF_CLIP    (1u << 15)   /* surface has custom clippers                                        */
+#define QR_OPF_CONIC   (1u << 16)   /* conic singularity fix applies (cones, hyper-cylinders)             */
+
+/* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
+
+struct CClip                    /* 16 B */
+{
+    uint32_t op;                /* QR_CL_* | flags                                                        */
+    uint32_t srf;               /* byte offset of the clipper's DSurf                                     */
+    uint32_t aux;               /* spare                                                                  */
+    uint32_t pad;
+};
+#define QR_CL_END      0u
+#define QR_CL_PLANE    1u       /* PL_clp: f = +-(x_k)                                                    */
+#define QR_CL_QUADJ    2u       /* QD_clp with the linear term (scj)                                      */
+#define QR_CL_QUAD     3u       /* QD_clp without                                                         */
+#define QR_CL_ENTER    4u       /* accumulator enter marker, tracer.h:79                                  */
+#define QR_CL_LEAVE    5u       /* accumulator leave marker                                               */
+#define QR_CL_TRNODE   6u       /* trnode of the clipper list: transform the hit once, cache              */
+#define QR_CL_TRSAME   7u       /* the surface's own trnode: reuse the surface's local hit                 */
+#define QR_CL_TYPE(op) ((op) & 7u)
+#define QR_CLF_INNER   (1u << 3)    /* data < 0 (MINUS_INNER): keep f >= 0, else keep f <= 0              */
+#define QR_CLM_SHIFT   4            /* bits 4-5: QR_OPM_* -- NONE: hit - pos, CACHED: cached - pos, OWN: M (hit - pos) */
+#define QR_CL_MODE(op) (((op) >> QR_CLM_SHIFT) & 3u)
+#define QR_CLF_FULLM   (1u << 6)
+#define QR_CL_AXK(op)  (((op) >> 8) & 3u)
+#define QR_CLF_SGNK    (1u << 10)
+#define QR_CLF_CDEF    (1u << 11)   /* ENTER: the owner's c_def mask is all ones                          */
+
+/* ---- light lists ----------------------------------------------------------------------------------------- */
+
+struct CLight { uint32_t lgt; uint32_t shadow; };     /* byte offsets of the qr_light (| QR_CLIGHT_LAST on the last entry) and of the shadow list (0 none) */
+#define QR_CLIGHT_LAST 1u
+
+/* ---- per-surface records --------------------------------------------------------------------------------- */
+
+/* walk record, 128 B: a plane needs the first 48 bytes, every other solver the first 80 */
+struct DSurf
+{
+    float pos[3]; uint32_t clip;        /*  0  clip: byte offset of the clipper program or 0               */
+    float min[3]; float d_eps;          /*  4  unclipped axes hold -inf / +inf                               */
+    float max[3]; float t_eps;          /*  8                                                              */
+    float sci[4];                       /* 12                                                              */
+    float scj[3]; uint32_t flags;       /* 16  DF_* below                                                    */
+    float tci[3]; uint32_t trn;         /* 20  trn: byte offset of the trnode's DSurf (shading normals)      */
+    float tcj[3]; int32_t props0;       /* 24                                                              */
+    float tck[3]; int32_t props1;       /* 28                                                              */
+};
+
+#define DF_CONIC(f)   (((f) >> 6) & 3u)
+#define DF_TRM(f)     (((f) >> 8) & 3u)
+#define DF_SHIFT(f)   (((f) >> 10) & 1u)
+#define DF_MAP(f, n)  (((f) >> (11 + 2 * (n))) & 3u)
+#define DF_SGN(f, n)  ((((f) >> (17 + (n))) & 1u) ? 0x80000000u : 0u)
+#define DF_SOLVER(f)  (((f) >> 20) & 3u)
+#define DF_NKIND(f)   (((f) >> 22) & 3u)
+#define DF_CKIND(f)   (((f) >> 24) & 3u)
+#define DF_ARRAY(f)   (((f) >> 26) & 1u)
+#define DF_CDEF(f)    (((f) >> 28) & 1u)
+
+/* shading record, 32 B */
+struct DShade
+{
+    uint32_t mat[2];            /* byte offsets of the outer / inner material                              */
+    uint32_t lgt[2];            /* byte offsets of the outer / inner light list (0 none)                   */
+    uint32_t lst[2];            /* byte offsets of the outer / inner surface list for secondary rays       */
+    uint32_t srf;               /* byte offset of the DSurf                                                 */
+    uint32_t pad;
+};
+
+/* blob layout: header at offset 0, the DSurf array right behind it */
+#define QR_OFF_SRF 256u
+/* blob header at offset 0 */
+struct DevHeader
+{
+    qr_frame fr;                /* camera + frame geometry, read with scalar loads                          */
+    uint32_t off_shade;         /* DShade array, indexed by surface index (hit -> shading)                  */
+    uint32_t off_tiles;         /* tile heads as byte offsets of lists (0 = empty tile)                     */
+    uint32_t off_order;         /* whole-frame wave schedule                                                */
+    uint32_t n_blocks;
+    uint32_t pad[11];
+};
+
+#endif /* QR_PROGRAM_H */

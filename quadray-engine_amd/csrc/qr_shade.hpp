@@ -30,7 +30,7 @@ struct Shaded
     float c_trn, c_rfl, x0;
     bool want_tr;           /* refraction child exists (M_TRN, not opaque)    */
     bool want_rf;           /* reflection pass applies (RF_ini reached)       */
-    int  lst_tr, lst_rf;
+    u32  lst_tr, lst_rf;    /* byte offsets of the children's list programs */
 };
 
 struct Counters { u32 primary, shadow, reflect, refract; };
@@ -38,25 +38,27 @@ struct Counters { u32 primary, shadow, reflect, refract; };
 /* state of the enclosing recursion that only has to survive a shade() call */
 struct Outer { V3 ret; int hit_id, sp, mode; };
 
-template <bool COUNT, bool DIV>
-__device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r, const Hit &h,
+template <bool COUNT>
+__device__ __forceinline__ void shade(const Ctx &cx, bool act, const Ray &r, const Hit &h,
                                       Shaded &o, Counters &cnt)
 {
-    /* per-lane (divergent) material data; everything below is lane-private
-     * except the wave-wide shadow traversals in the light loop */
+    /* per-lane (divergent) material data: vector loads at byte offsets from the blob base; everything
+     * below is lane-private except the wave-wide shadow traversals in the light loop */
+    const BaseP B = cx.B;
+    const char *__restrict__ G = cx.G;
+    const FrmP fr = c_frm(B);
     const int si = act ? h.si : 0;
     const int side = h.side;
-    const DSurf *__restrict__ s = &sc.srf[si];
-    const DShade *__restrict__ sd = &sc.shd[si];
-    const FrmP fr = c_frm(sc);
+    const DShade *__restrict__ sd = (const DShade *)(G + (cx.off_shade + (u32)si * (u32)sizeof(DShade)));
+    const DSurf *__restrict__ s = (const DSurf *)(G + (QR_OFF_SRF + (u32)si * (u32)sizeof(DSurf)));
 
     V3 nrm = {0, 0, 1};
     V3 tex = {0, 0, 0};
     V3 col = {0, 0, 0};
     V3 hit = {0, 0, 0};
     int props = 0;
-    int mi = 0;
-    int le = QR_NULL;
+    u32 mo = 0;                 /* byte offset of the hit side's material */
+    u32 le = 0;                 /* byte offset of the current light-list entry, 0 = none */
 
     if (act)
     {
@@ -67,7 +69,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         x6 = r.dir.z * t; hit.z = x6 + r.org.z;
 
         props = side | (side ? s->props1 : s->props0);
-        mi = sd->mat[side];
+        mo = sd->mat[side];
         const u32 fl = s->flags;
         const u32 tside = side ? QR_SMASK : 0u;
         const int has_trm = (int)DF_TRM(fl);
@@ -104,7 +106,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         if (has_trm != 0)
         {
             /* MT_nrm 2184-2263: transposed trnode matrix */
-            const DSurf *__restrict__ tr = &sc.srf[s->trnode];
+            const DSurf *__restrict__ tr = (const DSurf *)(G + s->trn);
             const int ttrm = (int)DF_TRM(tr->flags);
             x1 = ln.x; x2 = ln.y; x3 = ln.z;
             x4 = tr->tci[0] * x1;
@@ -130,7 +132,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         }
 
         /* MT_tex 2293-2327, PAINT_FRAG / PAINT_COLX 653-673 */
-        const qr_material *__restrict__ mt = &sc.mat[mi];
+        const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
         u32 toff = 0;
         if (props & QR_PROP_TEXTURE)
         {
@@ -142,7 +144,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
             const int32_t iv = cvt_floor(x5) & (int32_t)mt->ymask;
             toff = (u32)iu + ((u32)iv << (mt->yshft & 31));
         }
-        const u32 texel = sc.texels[mt->tex + (int32_t)toff];
+        const u32 texel = *(const u32 *)(G + ((u32)mt->tex + toff * 4u));
         const u32 cmask = mt->cmask;
         const float clampv = mt->clamp;
         tex.x = (float)(int32_t)((texel >> 16) & cmask) / clampv;
@@ -156,20 +158,19 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         }
         else
         {
-            col.x = tex.x * fr->amb[0];
-            col.y = tex.y * fr->amb[1];
-            col.z = tex.z * fr->amb[2];
-            le = sd->lst[side * 2];
+            col.x = tex.x * fr->fr.amb[0];
+            col.y = tex.y * fr->fr.amb[1];
+            col.z = tex.z * fr->fr.amb[2];
+            le = sd->lgt[side];
         }
     }
 
-    /* lights, 2758-3156: wave-wide loop, per-lane light elements */
-    while (__any(le != QR_NULL))
+    /* lights, 2758-3156: wave-wide loop, per-lane light-list entries */
+    while (any_lane(le != 0))
     {
-        const bool has = le != QR_NULL;
-        const DCell cel = sc.elm[has ? le : 0];
-        qr_elem el; el.simd = cel.simd; el.data = cel.data; el.next = cel.next; el.kind = cel.kind;
-        const qr_light *__restrict__ lg = &sc.lgt[has ? el.simd : 0];
+        const bool has = le != 0;
+        const CLight cl = *(const CLight *)(G + le);            /* lanes without a light read the header: harmless */
+        const qr_light *__restrict__ lg = (const qr_light *)(G + (has ? (cl.lgt & ~QR_CLIGHT_LAST) : 0u));
         V3 L = {0, 0, 0};
         float dot = 0.0f;
         bool lm = false;
@@ -185,28 +186,21 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
         }
         Ray sr;
         sr.org = hit; sr.dir = L; sr.tmin = 0.0f; sr.tmax = lg->t_max;
-        sr.list = el.data; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
+        sr.list = has ? cl.shadow : 0u; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
         Hit sh; bool occ;
         if (COUNT) { if (lm) cnt.shadow++; }
         if (QR_KNOB(2)) lm = false;
         if (QR_KNOB(1)) occ = false; else
         {
-#ifdef QR_X_NOSHADOW
-            occ = false; sh.si = 0;
-#else
-#ifdef QR_WAVETIME
-            const unsigned long long wt_a = __builtin_amdgcn_s_memrealtime();
+            traverse<true>(B, lm, sr, sh, occ
+#ifdef QR_STATS
+                                  , cx.stats
 #endif
-            traverse<true, DIV>(sc, lm, sr, sh, occ);
-#ifdef QR_WAVETIME
-            if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
-                sc.stats[28 + ((size_t)blockIdx.x * (QR_BLOCK / 64) + (threadIdx.x >> 6)) * QR_WT_SLOTS + 10] += __builtin_amdgcn_s_memrealtime() - wt_a;
-#endif
-#endif
+                                  );
         }
         if (lm && !occ)
         {
-            const qr_material *__restrict__ mt = &sc.mat[mi];
+            const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
             float x0, x1, x2, x3, x4, x5, x6, x7;
             x1 = L.x; x4 = x1 * x1;
             x2 = L.y; x5 = x2 * x2;
@@ -302,18 +296,18 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
                 col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
             }
         }
-        le = has ? el.next : QR_NULL;
+        le = (has && !(cl.lgt & QR_CLIGHT_LAST)) ? le + (u32)sizeof(CLight) : 0u;
     }
 
     o.col = col; o.hit = hit; o.loc = h.loc;
     o.tdir = {0, 0, 0}; o.rdir = {0, 0, 0};
     o.c_trn = 0.0f; o.c_rfl = 0.0f; o.x0 = 0.0f;
     o.want_tr = false; o.want_rf = false;
-    o.lst_tr = QR_NULL; o.lst_rf = QR_NULL;
+    o.lst_tr = 0; o.lst_rf = 0;
 
     if (act)
     {
-        const qr_material *__restrict__ mt = &sc.mat[mi];
+        const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
         const float m_trn_c = mt->c_trn, m_rfl_c = mt->c_rfl;
         float c_trn = m_trn_c, c_rfl = m_rfl_c;
         float x0 = 0.0f, x1, x2, x3, x4 = 0.0f, x5, x6 = 0.0f, x7 = 0.0f;
@@ -385,7 +379,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
                 }
                 o.want_tr = m_trn;
                 o.tdir = nd;
-                o.lst_tr = sd->lst[(1 - side) * 2 + 1];
+                o.lst_tr = sd->lst[1 - side];
             }
         }
 
@@ -458,7 +452,7 @@ __device__ __forceinline__ void shade(const DevScene &sc, bool act, const Ray &r
                 c_rfl = m_rfl_c + x0;
             }
             o.want_rf = true;
-            o.lst_rf = sd->lst[side * 2 + 1];
+            o.lst_rf = sd->lst[side];
         }
         o.c_trn = c_trn;
         o.c_rfl = c_rfl;
