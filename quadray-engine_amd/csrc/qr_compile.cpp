@@ -203,12 +203,12 @@ struct Builder
             bool trnode_cell = false;
             if (!arr && local_obj != QR_NULL)
             {
-                mode = QR_OPM_CACHED;
+                mode = QR_OPF_CACHED;
                 if (t.e == local_obj) local_obj = QR_NULL;
             }
-            else if (s.has_trm == 0) mode = QR_OPM_NONE;
-            else if (arr) { mode = QR_OPM_NONE; trnode_cell = true; local_obj = el.data; }
-            else mode = QR_OPM_OWN;
+            else if (s.has_trm == 0) mode = 0;
+            else if (arr) { mode = 0; trnode_cell = true; local_obj = el.data; }
+            else mode = QR_OPF_OWN;
             lo_self[i] = local_obj;
             const int solver = real ? s.srf_t[0] : 0;
             if (trnode_cell)
@@ -216,35 +216,36 @@ struct Builder
                 if (bv) throw Fail{QR_ERR_UNSUP, "bounding volume on a transformed array element"};
                 if (el.data == QR_NULL || chain_stamp[el.data] != stamp || chain_pos[el.data] < i)
                     throw Fail{QR_ERR_ARG, "trnode's last element is not behind it in its list"};
-                type = QR_OP_TRNODE; t.last = chain_pos[el.data];
+                type = QR_OPT_TRNODE; t.last = chain_pos[el.data];
             }
             else if (bv)
             {
                 if (el.data == QR_NULL || chain_stamp[el.data] != stamp || chain_pos[el.data] < i)
                     throw Fail{QR_ERR_ARG, "array's last element is not behind it in its list"};
-                type = QR_OP_BV; t.last = chain_pos[el.data];
+                type = QR_OPT_BV; t.last = chain_pos[el.data];
             }
-            else if (solver == 1) type = QR_OP_PLANE;
-            else if (solver == 2) type = QR_OP_QUADRIC;
-            else if (solver == 3) type = QR_OP_TWOPLANE;
-            else { type = QR_OP_END; t.emit = false; }    /* marker: touches only state nobody reads */
-            if (t.emit && type != QR_OP_TRNODE && ((s.shift != 0) != (mode != QR_OPM_NONE)))
+            else if (solver == 1) type = QR_OPT_PLANE;
+            else if (solver == 2) type = QR_OPT_QUADRIC;
+            else if (solver == 3) type = QR_OPT_TWOPLANE;
+            else { type = 0; t.emit = false; }          /* marker: touches only state nobody reads */
+            if (t.emit && type != QR_OPT_TRNODE && ((s.shift != 0) != (mode != 0)))
                 throw Fail{QR_ERR_UNSUP, "surface reads the trnode-space diff outside a trnode (or the reverse)"};
-            uint32_t op = type | (mode << QR_OPM_SHIFT);
+            uint32_t op = type | mode;
             if (s.has_trm != 1) op |= QR_OPF_FULLM;
-            if (type == QR_OP_PLANE || type == QR_OP_QUADRIC || type == QR_OP_TWOPLANE)
+            if (type & QR_OPT_SOLVER)
             {
-                op |= ((s.axes >> 4) & 3u) << 8;
+                const uint32_t ak = (s.axes >> 4) & 3u, ai = (s.axes >> 0) & 3u;
+                if (ak == 0) op |= QR_OPF_KX; else if (ak == 1) op |= QR_OPF_KY;
                 if ((s.axes >> 10) & 1u) op |= QR_OPF_SGNK;
-                op |= ((s.axes >> 0) & 3u) << 11;
+                if (ai == 0) op |= QR_OPF_IX; else if (ai == 1) op |= QR_OPF_IY;
                 auto no_shadow = [](int p) { return (p & QR_PROP_LIGHT) || ((p & QR_PROP_TRANSP) && !(p & QR_PROP_REFRACT)); };
                 const bool n0 = no_shadow(s.props[0]), n1 = no_shadow(s.props[1]);
-                op |= (n0 && n1 ? 1u : (!n0 && !n1 ? 0u : 2u)) << 13;
+                if (n0 && n1) op |= QR_OPF_NOSHAD; else if (n0 || n1) op |= QR_OPF_SIDESHAD;
                 if (s.clip != QR_NULL) op |= QR_OPF_CLIP;
                 if (s.conic != 0) op |= QR_OPF_CONIC;
                 const bool open_shape = s.srf_t[0] == 1 || !(s.sci[0] > 0.0f && s.sci[1] > 0.0f && s.sci[2] > 0.0f);
                 const bool want = cull_mode >= 3 || (cull_mode == 2 && open_shape) || (cull_mode == 1 && s.srf_t[0] == 1);
-                if (want && bs[el.simd].r < 1e30f) op |= QR_OPF_CULL;
+                if (want && bs[el.simd].r < 1e18f) op |= QR_OPF_CULL;
             }
             t.op = op;
             lo_after[i] = local_obj;
@@ -256,7 +257,7 @@ struct Builder
             for (int i = 0; i < n; i++)
             {
                 while (!open.empty() && open.back() < i) open.pop_back();
-                if (QR_OP_TYPE(ch[i].op) != QR_OP_BV || !ch[i].emit) continue;
+                if (!(ch[i].op & QR_OPT_BV) || !ch[i].emit) continue;
                 const int j = ch[i].last;
                 int lo = lo_self[i];
                 if (lo == ch[j].e) lo = QR_NULL;
@@ -277,10 +278,15 @@ struct Builder
             if (!ch[i].emit) continue;
             CCell c;
             memset(&c, 0, sizeof(c));
-            c.op = ch[i].op; c.si = ch[i].si; c.srf = srf_off(ch[i].si);
-            if (ch[i].last != QR_NULL) c.end = off + (uint32_t)emit_idx[ch[i].last + 1] * (uint32_t)sizeof(CCell);
+            c.op = ch[i].op; c.srf = srf_off(ch[i].si);
+            if (c.op & QR_OPT_BV) c.end = off + (uint32_t)emit_idx[ch[i].last + 1] * (uint32_t)sizeof(CCell);
             c.r = __builtin_inff();
-            if (c.op & QR_OPF_CULL) { const BSphere &b = bs[ch[i].si]; c.cx = b.c[0]; c.cy = b.c[1]; c.cz = b.c[2]; c.r = b.r; }
+            if (c.op & QR_OPF_CULL)
+            {
+                const BSphere &bsp = bs[ch[i].si];
+                c.cx = bsp.c[0]; c.cy = bsp.c[1]; c.cz = bsp.c[2]; c.r = bsp.r;
+                c.r2 = bsp.r * bsp.r; c.r2x = c.r2 * 1.01f;
+            }
             *at<CCell>(off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell)) = c;
         }
         /* END cell: already zero */
@@ -305,7 +311,7 @@ struct Builder
             CClip c = {0, 0, 0, 0};
             if (el.simd == QR_NULL)
             {
-                c.op = el.data > 0 ? QR_CL_LEAVE : (QR_CL_ENTER | (cdef ? QR_CLF_CDEF : 0u));
+                c.op = el.data > 0 ? QR_CLT_LEAVE : (QR_CLT_ENTER | (cdef ? QR_CLF_CDEF : 0u));
                 prog.push_back(c);
                 continue;
             }
@@ -316,13 +322,13 @@ struct Builder
             uint32_t mode;
             if (!karr)
             {
-                if (redx != QR_NULL) { mode = QR_OPM_CACHED; if (e == redx) redx = QR_NULL; }
-                else mode = k.has_trm != 0 ? QR_OPM_OWN : QR_OPM_NONE;
+                if (redx != QR_NULL) { mode = QR_CLF_CACHED; if (e == redx) redx = QR_NULL; }
+                else mode = k.has_trm != 0 ? QR_CLF_OWN : 0u;
             }
             else if (el.simd == s.trnode)
             {
                 if (s.has_trm == 0) throw Fail{QR_ERR_UNSUP, "clipper trnode shared with an untransformed surface"};
-                c.op |= QR_CL_TRSAME; redx = el.data; prog.push_back(c); continue;
+                c.op |= QR_CLT_TRSAME; redx = el.data; prog.push_back(c); continue;
             }
             else
             {
@@ -332,19 +338,20 @@ struct Builder
                     if (redx != QR_NULL) throw Fail{QR_ERR_UNSUP, "untransformed array inside a clipper trnode"};
                     continue;
                 }
-                c.op |= QR_CL_TRNODE; redx = el.data; prog.push_back(c); continue;
+                c.op |= QR_CLT_TRNODE; redx = el.data; prog.push_back(c); continue;
             }
             const int ckind = k.srf_t[2];
             if (ckind == 0) continue;                   /* no clip function: no effect */
-            if ((k.shift != 0) != (mode != QR_OPM_NONE))
+            if ((k.shift != 0) != (mode != 0))
                 throw Fail{QR_ERR_UNSUP, "clipper reads the trnode-space hit outside a trnode (or the reverse)"};
-            c.op |= (uint32_t)ckind | (mode << QR_CLM_SHIFT);
+            c.op |= (ckind == 1 ? QR_CLT_PLANE : ckind == 2 ? QR_CLT_QUADJ : QR_CLT_QUAD) | mode;
             if (el.data < 0) c.op |= QR_CLF_INNER;
-            c.op |= ((k.axes >> 4) & 3u) << 8;
+            const uint32_t ak = (k.axes >> 4) & 3u;
+            if (ak == 0) c.op |= QR_CLF_KX; else if (ak == 1) c.op |= QR_CLF_KY;
             if ((k.axes >> 10) & 1u) c.op |= QR_CLF_SGNK;
             prog.push_back(c);
         }
-        CClip endc = {QR_CL_END, 0, 0, 0};
+        CClip endc = {0, 0, 0, 0};
         prog.push_back(endc);
         const uint32_t off = alloc(prog.size() * sizeof(CClip), 16);
         memcpy(at<CClip>(off), prog.data(), prog.size() * sizeof(CClip));
@@ -570,19 +577,19 @@ int qr_program_verify(const QrProgram &p, std::string &err)
         {
             if ((size_t)o + 32 > limit) return "list runs off the image";
             const CCell *c = (const CCell *)(b.data() + o);
-            if (QR_OP_TYPE(c->op) == QR_OP_END) { end_cell = o; break; }
+            if (c->op == 0) { end_cell = o; break; }
         }
         for (o = off; o < end_cell; o += 32)
         {
             const CCell *c = (const CCell *)(b.data() + o);
-            const uint32_t t = QR_OP_TYPE(c->op);
-            if (t > QR_OP_TRNODE) return "bad opcode";
-            if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf))) return "cell surface offset out of range";
-            if (c->si < 0 || (uint32_t)c->si >= p.n_srf) return "cell surface index out of range";
-            if (t == QR_OP_BV && (c->end <= o || c->end > end_cell || (c->end & 31))) return "array end outside its list";
-            if (QR_OP_MODE(c->op) > QR_OPM_OWN) return "bad transform mode";
-            if (t == QR_OP_PLANE && QR_OP_AXK(c->op) > 2) return "bad plane axis";
-            if (t == QR_OP_TWOPLANE && (QR_OP_AXK(c->op) > 2 || QR_OP_AXI(c->op) > 2)) return "bad two-plane axes";
+            const uint32_t t = c->op & QR_OPT_MASK;
+            if (t == 0 || (t & (t - 1)) != 0) return "bad opcode";
+            if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf)) return "cell surface offset out of range";
+            if (t == QR_OPT_BV && (c->end <= o || c->end > end_cell || (c->end & 31))) return "array end outside its list";
+            if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
+            if ((c->op & QR_OPF_CULL) && !(t & QR_OPT_SOLVER)) return "cull flag on a cell without solver";
+            if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
+            if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";
         }
         return nullptr;
     };
@@ -612,10 +619,12 @@ int qr_program_verify(const QrProgram &p, std::string &err)
             {
                 if ((size_t)o + 16 > limit) return bad("clipper program runs off the image");
                 const CClip *c = (const CClip *)(b.data() + o);
-                const uint32_t t = QR_CL_TYPE(c->op);
-                if (t == QR_CL_END) break;
-                if (t != QR_CL_ENTER && t != QR_CL_LEAVE && !in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf))) return bad("clipper surface offset");
-                if (t == QR_CL_PLANE && QR_CL_AXK(c->op) > 2) return bad("bad clipper axis");
+                if (c->op == 0) break;
+                const uint32_t t = c->op & QR_CLT_MASK;
+                if (t == 0 || (t & (t - 1)) != 0) return bad("bad clipper opcode");
+                if (t != QR_CLT_ENTER && t != QR_CLT_LEAVE && (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf))) return bad("clipper surface offset");
+                if ((c->op & QR_CLF_KX) && (c->op & QR_CLF_KY)) return bad("bad clipper axis");
+                if ((c->op & QR_CLF_CACHED) && (c->op & QR_CLF_OWN)) return bad("bad clipper transform mode");
             }
         }
         for (int k = 0; k < 2; k++)

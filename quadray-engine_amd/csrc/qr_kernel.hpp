@@ -162,7 +162,7 @@ struct Ray
     V3 org, dir;            /* ctx_ORG, ctx_RAY_X..Z                          */
     float tmin, tmax;       /* ctx_T_MIN, initial ctx_T_BUF                   */
     u32 list;               /* byte offset of the list program, 0 = none      */
-    int osi;                /* ctx_PARAM(OBJ): originating surface or -1      */
+    u32 osrf;               /* ctx_PARAM(OBJ): byte offset of the originating surface's DSurf, 0 = none */
     int oflg;               /* ctx_PARAM(FLG) & 3: side | pass-thru           */
     V3 ploc;                /* parent's local hit (parent ctx_NRM_I..K)       */
 };
@@ -170,7 +170,7 @@ struct Ray
 struct Hit
 {
     float t;                /* final ctx_T_BUF                                */
-    int si;                 /* surface index or -1                            */
+    u32 srf;                /* byte offset of the hit surface's DSurf, 0 = none */
     int side;
     V3 loc;                 /* local (possibly conic-adjusted) hit, ctx_NEW   */
 };
@@ -272,7 +272,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         ray.dir.z = x3 + fr->fr.dir[2];
         ray.org.x = fr->fr.org[0]; ray.org.y = fr->fr.org[1]; ray.org.z = fr->fr.org[2];
         ray.tmin = fr->fr.t_min; ray.tmax = t_inf;
-        ray.osi = QR_NULL; ray.oflg = 0;
+        ray.osrf = 0; ray.oflg = 0;
         ray.ploc = {0, 0, 0};
         ray.list = 0;
         if (sched_head != QR_PER_LANE_TILE)
@@ -313,9 +313,10 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (wt_mid == 0) wt_mid = __builtin_amdgcn_s_memrealtime();
             wt_push++;
 #endif
-            const bool got = tr && h.si != QR_NULL && !QR_KNOB(4);
+            const bool got = tr && h.srf != 0 && !QR_KNOB(4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
-            if (got && sp == 0) hit_id = (h.si << 1) | h.side;
+            const int hsi = (int)((h.srf - QR_OFF_SRF) >> 7);          /* surface index: DSurf records are 128 B */
+            if (got && sp == 0) hit_id = (hsi << 1) | h.side;
 
             Shaded o;
             shade<COUNT>(cx, got, ray, h, o, cnt);
@@ -323,7 +324,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (got)
             {
                 const bool can_spawn = (depth - sp) != 0;
-                const int meta = (h.si << 4) | (h.side << 3) | (o.want_rf ? 4 : 0);
+                const int meta = (hsi << 4) | (h.side << 3) | (o.want_rf ? 4 : 0);
                 if (o.want_tr && can_spawn)
                 {
                     Frame &f = stk[sp];
@@ -335,7 +336,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                     f.meta = meta | 1;
                     sp++;
                     ray.org = o.hit; ray.dir = o.tdir; ray.tmin = 0.0f; ray.tmax = t_inf;
-                    ray.list = o.lst_tr; ray.osi = h.si; ray.oflg = h.side | FLAG_PASS_THRU;
+                    ray.list = o.lst_tr; ray.osrf = h.srf; ray.oflg = h.side | FLAG_PASS_THRU;
                     ray.ploc = o.loc;
                     mode = 0;
                     if (COUNT) cnt.refract++;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                         f.meta = meta | 2;
                             sp++;
                         ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = t_inf;
-                        ray.list = o.lst_rf; ray.osi = h.si; ray.oflg = h.side;
+                        ray.list = o.lst_rf; ray.osrf = h.srf; ray.oflg = h.side;
                         ray.ploc = o.loc;
                         mode = 0;
                         if (COUNT) cnt.reflect++;
@@ -401,7 +402,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                         ray.dir = {f.rdir[0], f.rdir[1], f.rdir[2]};
                         ray.tmin = 0.0f; ray.tmax = t_inf;
                         ray.list = ((const DShade *)(cx.G + (cx.off_shade + (u32)psi * (u32)sizeof(DShade))))->lst[pside];
-                        ray.osi = psi; ray.oflg = pside;
+                        ray.osrf = QR_OFF_SRF + ((u32)psi << 7); ray.oflg = pside;
                         ray.ploc = {f.loc[0], f.loc[1], f.loc[2]};
                         mode = 0;
                         if (COUNT) cnt.reflect++;

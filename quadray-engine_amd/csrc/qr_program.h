@@ -26,34 +26,39 @@
 
 struct CCell                    /* 32 B, 32-byte aligned */
 {
-    uint32_t op;                /* QR_OP_* | flags below                                                */
+    uint32_t op;                /* QR_OPT_* type bit | flags below; 0 ends the list                       */
     uint32_t srf;               /* byte offset of the surface's DSurf                                    */
-    uint32_t end;               /* BV / TRNODE: byte offset just behind the array's last cell            */
-    int32_t  si;                /* surface index (hit ids, own-surface test)                             */
+    union { uint32_t end;       /* BV: byte offset just behind the array's last cell                     */
+            float r2; };        /* cull cells: R^2 of the bounding sphere                                */
+    float    r2x;               /* cull cells: 1.01 R^2 (origin counts as outside the sphere beyond it)  */
     float    cx, cy, cz, r;     /* conservative world-space bounding sphere (QR_OPF_CULL cells)          */
 };
 
-#define QR_OP_END      0u       /* end of list                                                            */
-#define QR_OP_PLANE    1u       /* PL_ptr, tracer.cpp:4062-4136                                           */
-#define QR_OP_QUADRIC  2u       /* QD_ptr, 4378-4447                                                      */
-#define QR_OP_TWOPLANE 3u       /* TP_ptr, 4216-4277                                                      */
-#define QR_OP_BV       4u       /* AR_ptr bounding volume, 3955-4054                                      */
-#define QR_OP_TRNODE   5u       /* array element with a transform: fills the trnode cache, 1419-1556     */
-#define QR_OP_TYPE(op) ((op) & 7u)
+/* cell type: one bit each, so that the walk tests them with s_bitcmp in the order of their frequency
+ * (a dense enum makes the compiler build a compare tree) */
+#define QR_OPT_PLANE    (1u << 0)   /* PL_ptr, tracer.cpp:4062-4136                                       */
+#define QR_OPT_QUADRIC  (1u << 1)   /* QD_ptr, 4378-4447                                                  */
+#define QR_OPT_TWOPLANE (1u << 2)   /* TP_ptr, 4216-4277                                                  */
+#define QR_OPT_BV       (1u << 3)   /* AR_ptr bounding volume, 3955-4054                                  */
+#define QR_OPT_TRNODE   (1u << 4)   /* array element with a transform: fills the trnode cache, 1419-1556 */
+#define QR_OPT_MASK     31u
+#define QR_OPT_SOLVER   (QR_OPT_PLANE | QR_OPT_QUADRIC | QR_OPT_TWOPLANE)
 
-#define QR_OPF_CULL    (1u << 3)    /* bounding-sphere cull applies                                       */
-#define QR_OPM_SHIFT   4            /* bits 4-5: which diff / ray the cell reads                           */
-#define QR_OPM_NONE    0u           /*   world: diff = org - pos, ray = dir                                */
-#define QR_OPM_CACHED  1u           /*   inside a trnode: diff = cached - pos, ray = cached                */
-#define QR_OPM_OWN     2u           /*   own transform: diff = M (org - pos), ray = M dir                  */
-#define QR_OP_MODE(op) (((op) >> QR_OPM_SHIFT) & 3u)
-#define QR_OPF_FULLM   (1u << 6)    /* transform has rotation (a_map[L] != 1): full 3x3, else diagonal    */
-#define QR_OP_AXK(op)  (((op) >> 8) & 3u)      /* plane: axis k (two-plane: axis k too)                   */
-#define QR_OPF_SGNK    (1u << 10)               /* plane: sign of axis k                                   */
-#define QR_OP_AXI(op)  (((op) >> 11) & 3u)     /* two-plane: axis i                                       */
-#define QR_OP_SHAD(op) (((op) >> 13) & 3u)     /* CHECK_SHAD 549-589: 0 a hit occludes, 1 never, 2 by side */
-#define QR_OPF_CLIP    (1u << 15)   /* surface has custom clippers                                        */
-#define QR_OPF_CONIC   (1u << 16)   /* conic singularity fix applies (cones, hyper-cylinders)             */
+#define QR_OPF_CULL    (1u << 5)    /* bounding-sphere cull applies                                       */
+/* which diff / ray the cell reads: neither bit: world (diff = org - pos, ray = dir) */
+#define QR_OPF_CACHED  (1u << 6)    /*   inside a trnode: diff = cached - pos, ray = cached                */
+#define QR_OPF_OWN     (1u << 7)    /*   own transform: diff = M (org - pos), ray = M dir                  */
+#define QR_OPF_LOCAL   (QR_OPF_CACHED | QR_OPF_OWN)
+#define QR_OPF_FULLM   (1u << 8)    /* transform has rotation (a_map[L] != 1): full 3x3, else diagonal    */
+#define QR_OPF_KX      (1u << 9)    /* plane / two-plane: axis k is x                                     */
+#define QR_OPF_KY      (1u << 10)   /*                    axis k is y (neither: z)                        */
+#define QR_OPF_SGNK    (1u << 11)   /* plane: sign of axis k                                              */
+#define QR_OPF_IX      (1u << 12)   /* two-plane: axis i is x                                             */
+#define QR_OPF_IY      (1u << 13)   /*            axis i is y (neither: z)                                */
+#define QR_OPF_NOSHAD  (1u << 14)   /* CHECK_SHAD 549-589: a hit never occludes                           */
+#define QR_OPF_SIDESHAD (1u << 15)  /*   ... occludes depending on the side hit (look at the props)       */
+#define QR_OPF_CLIP    (1u << 16)   /* surface has custom clippers                                        */
+#define QR_OPF_CONIC   (1u << 17)   /* conic singularity fix applies (cones, hyper-cylinders)             */
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
 
@@ -64,22 +69,23 @@ struct CClip                    /* 16 B */
     uint32_t aux;               /* spare                                                                  */
     uint32_t pad;
 };
-#define QR_CL_END      0u
-#define QR_CL_PLANE    1u       /* PL_clp: f = +-(x_k)                                                    */
-#define QR_CL_QUADJ    2u       /* QD_clp with the linear term (scj)                                      */
-#define QR_CL_QUAD     3u       /* QD_clp without                                                         */
-#define QR_CL_ENTER    4u       /* accumulator enter marker, tracer.h:79                                  */
-#define QR_CL_LEAVE    5u       /* accumulator leave marker                                               */
-#define QR_CL_TRNODE   6u       /* trnode of the clipper list: transform the hit once, cache              */
-#define QR_CL_TRSAME   7u       /* the surface's own trnode: reuse the surface's local hit                 */
-#define QR_CL_TYPE(op) ((op) & 7u)
-#define QR_CLF_INNER   (1u << 3)    /* data < 0 (MINUS_INNER): keep f >= 0, else keep f <= 0              */
-#define QR_CLM_SHIFT   4            /* bits 4-5: QR_OPM_* -- NONE: hit - pos, CACHED: cached - pos, OWN: M (hit - pos) */
-#define QR_CL_MODE(op) (((op) >> QR_CLM_SHIFT) & 3u)
-#define QR_CLF_FULLM   (1u << 6)
-#define QR_CL_AXK(op)  (((op) >> 8) & 3u)
-#define QR_CLF_SGNK    (1u << 10)
-#define QR_CLF_CDEF    (1u << 11)   /* ENTER: the owner's c_def mask is all ones                          */
+/* op == 0 ends the program; one type bit each */
+#define QR_CLT_PLANE   (1u << 0)    /* PL_clp: f = +-(x_k)                                                */
+#define QR_CLT_QUADJ   (1u << 1)    /* QD_clp with the linear term (scj)                                  */
+#define QR_CLT_QUAD    (1u << 2)    /* QD_clp without                                                     */
+#define QR_CLT_ENTER   (1u << 3)    /* accumulator enter marker, tracer.h:79                              */
+#define QR_CLT_LEAVE   (1u << 4)    /* accumulator leave marker                                           */
+#define QR_CLT_TRNODE  (1u << 5)    /* trnode of the clipper list: transform the hit once, cache          */
+#define QR_CLT_TRSAME  (1u << 6)    /* the surface's own trnode: reuse the surface's local hit             */
+#define QR_CLT_MASK    127u
+#define QR_CLF_INNER   (1u << 7)    /* data < 0 (MINUS_INNER): keep f >= 0, else keep f <= 0              */
+#define QR_CLF_CACHED  (1u << 8)    /* hit in the cached clipper trnode's space - pos                     */
+#define QR_CLF_OWN     (1u << 9)    /* M (hit - pos); neither: hit - pos                                  */
+#define QR_CLF_FULLM   (1u << 10)
+#define QR_CLF_KX      (1u << 11)
+#define QR_CLF_KY      (1u << 12)
+#define QR_CLF_SGNK    (1u << 13)
+#define QR_CLF_CDEF    (1u << 14)   /* ENTER: the owner's c_def mask is all ones                          */
 
 /* ---- light lists ----------------------------------------------------------------------------------------- */
 

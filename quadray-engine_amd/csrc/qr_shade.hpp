@@ -47,10 +47,10 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, const Ray &r, con
     const BaseP B = cx.B;
     const char *__restrict__ G = cx.G;
     const FrmP fr = c_frm(B);
-    const int si = act ? h.si : 0;
+    const u32 hsrf = act ? h.srf : QR_OFF_SRF;          /* lanes without a hit read surface 0: harmless */
     const int side = h.side;
-    const DShade *__restrict__ sd = (const DShade *)(G + (cx.off_shade + (u32)si * (u32)sizeof(DShade)));
-    const DSurf *__restrict__ s = (const DSurf *)(G + (QR_OFF_SRF + (u32)si * (u32)sizeof(DSurf)));
+    const DShade *__restrict__ sd = (const DShade *)(G + (cx.off_shade + ((hsrf - QR_OFF_SRF) >> 2)));   /* 32 B per 128 B */
+    const DSurf *__restrict__ s = (const DSurf *)(G + hsrf);
 
     V3 nrm = {0, 0, 1};
     V3 tex = {0, 0, 0};
@@ -186,7 +186,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, const Ray &r, con
         }
         Ray sr;
         sr.org = hit; sr.dir = L; sr.tmin = 0.0f; sr.tmax = lg->t_max;
-        sr.list = has ? cl.shadow : 0u; sr.osi = si; sr.oflg = side; sr.ploc = h.loc;
+        sr.list = has ? cl.shadow : 0u; sr.osrf = hsrf; sr.oflg = side; sr.ploc = h.loc;
         Hit sh; bool occ;
         if (COUNT) { if (lm) cnt.shadow++; }
         if (QR_KNOB(2)) lm = false;

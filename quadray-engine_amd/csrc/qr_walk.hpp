@@ -15,18 +15,26 @@
 #ifndef QR_WALK_HPP
 #define QR_WALK_HPP
 
-/* wave-level "any": one s_and + s_cmp on the lane mask (HIP's __any goes through a 0/1 VGPR) */
-__device__ __forceinline__ bool any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+/*
+ * Lane masks are kept as 64-bit scalars: a compare lands in an SGPR pair (`ballot` of a compare is the
+ * v_cmp itself), logic is s_and / s_or / s_andn2, "any lane" is one s_cmp, and `lane_of` turns a mask back
+ * into a per-lane predicate at no cost (the SGPR pair IS the predicate).  Masks only hold lanes that were
+ * active where they were computed.
+ */
+typedef unsigned long long lm_t;
+#define LM(cond) __builtin_amdgcn_ballot_w64(cond)
+__device__ __forceinline__ bool lane_of(lm_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ bool any_lane(bool b) { return LM(b) != 0ull; }
 
 /* what clip() needs to know about the candidate's surface space */
 struct ClipIn
 {
-    V3 df, ry;              /* the diff / ray the solver read (trnode space when mode != NONE)               */
-    bool dmask;             /* quadric: near-zero discriminant lanes (conic fix)                           */
+    V3 df, ry;              /* the diff / ray the solver read (trnode space for QR_OPF_LOCAL cells)        */
+    lm_t dmask;             /* quadric: near-zero discriminant lanes (conic fix)                           */
     u32 amask;              /* quadric: sign of `a`                                                        */
 };
 
-/* the first 48 / 80 bytes of a DSurf in SGPRs */
+/* the first 80 bytes of a DSurf in SGPRs */
 struct SurfS
 {
     float pos0, pos1, pos2; u32 clip;
@@ -71,26 +79,28 @@ __device__ __forceinline__ V3 xform(BaseP B, u32 off, bool full, V3 in)
 }
 
 __device__ __forceinline__ float sel3(float a, float b, float c, u32 i) { return i == 0 ? a : i == 1 ? b : c; }
+/* component by one-hot axis flags (x, y, else z): two v_cndmask on scalar conditions */
+__device__ __forceinline__ float axis3(const V3 &v, bool is_x, bool is_y) { return is_x ? v.x : (is_y ? v.y : v.z); }
 
 /* ------------------------------------------------------------------------ */
 /* CC_clp, tracer.cpp:1597-2160.  Returns the lanes of `m` whose hit at `t`  */
 /* survives; `loc` is the local hit (ctx_NEW_* of the surface's space).      */
 /* ------------------------------------------------------------------------ */
-__device__ __forceinline__ bool clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
-                                     const ClipIn &ci, float t, int side, bool m, V3 &loc)
+__device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
+                                     const ClipIn &ci, float t, int side, lm_t m, V3 &loc)
 {
-    const bool local = QR_OP_MODE(op) != QR_OPM_NONE;     /* the surface lives in a trnode's space */
     float x4, x5, x6;
     V3 hit;
 
-    m = m && cgt(tbuf, t) && clt(r.tmin, t);
+    m &= LM(cgt(tbuf, t)) & LM(clt(r.tmin, t));
 
     x4 = r.dir.x * t; x4 = x4 + r.org.x; hit.x = x4;
     x5 = r.dir.y * t; x5 = x5 + r.org.y; hit.y = x5;
     x6 = r.dir.z * t; x6 = x6 + r.org.z; hit.z = x6;
 
-    if (local)
+    if (op & QR_OPF_LOCAL)
     {
+        /* the surface lives in a trnode's space */
         x4 = ci.ry.x * t; x4 = x4 + ci.df.x;
         x5 = ci.ry.y * t; x5 = x5 + ci.df.y;
         x6 = ci.ry.z * t; x6 = x6 + ci.df.z;
@@ -113,99 +123,106 @@ __device__ __forceinline__ bool clip(BaseP B, const SurfS &s, u32 op, const Ray 
         x1 = vget(nw, (int)mi); x1 = x1 * x1; x0 = x1;
         if (conic != 2) { x2 = vget(nw, (int)mj); x2 = x2 * x2; x0 = x0 + x2; }
         x3 = vget(nw, (int)mk); x3 = x3 * x3; x0 = x0 + x3;
-        const bool hm = clt(x0, s.t_eps) && ci.dmask;
-        if (hm)
+        const lm_t hm = LM(clt(x0, s.t_eps)) & ci.dmask;
+        if (hm != 0)
         {
-            const u32 sm = QR_SMASK;
-            const float one = 1.0f;
-            float r4;
-            x2 = 0.0f;
-            x1 = u2f((f2u(vget(ci.df, (int)mi)) & sm) ^ f2u(one));
-            x3 = sel3(s.sci0, s.sci1, s.sci2, mi);
-            r4 = one;
-            if (conic != 2)
+            if (lane_of(hm))
             {
-                x2 = u2f((f2u(vget(ci.df, (int)mj)) & sm) ^ f2u(one));
-                x3 = x3 + sel3(s.sci0, s.sci1, s.sci2, mj);
-                r4 = r4 + one;
+                const u32 sm = QR_SMASK;
+                const float one = 1.0f;
+                float r4;
+                x2 = 0.0f;
+                x1 = u2f((f2u(vget(ci.df, (int)mi)) & sm) ^ f2u(one));
+                x3 = sel3(s.sci0, s.sci1, s.sci2, mi);
+                r4 = one;
+                if (conic != 2)
+                {
+                    x2 = u2f((f2u(vget(ci.df, (int)mj)) & sm) ^ f2u(one));
+                    x3 = x3 + sel3(s.sci0, s.sci1, s.sci2, mj);
+                    r4 = r4 + one;
+                }
+                x3 = x3 / sel3(s.sci0, s.sci1, s.sci2, mk);
+                x3 = fxor(x3, sm);
+                float y6 = x3;
+                x3 = __builtin_sqrtf(x3);
+                y6 = y6 + r4;
+                r4 = rsq(y6);
+                r4 = r4 * s.t_eps;
+                x1 = x1 * r4; x2 = x2 * r4; x3 = x3 * r4;
+
+                const u32 tside = side ? sm : 0u;
+                x3 = fxor(x3, f2u(vget(ci.df, (int)mk)) & sm);
+                x3 = fxor(x3, (tside & ci.amask) ^ ci.amask);
+                const u32 u5 = (tside | ci.amask) ^ ci.amask;
+                x1 = fxor(x1, u5);
+                x2 = fxor(x2, u5);
+
+                vset(nw, (int)mi, x1);
+                if (conic != 2) vset(nw, (int)mj, x2);
+                vset(nw, (int)mk, x3);
+                x4 = nw.x; x5 = nw.y; x6 = nw.z;
             }
-            x3 = x3 / sel3(s.sci0, s.sci1, s.sci2, mk);
-            x3 = fxor(x3, sm);
-            float y6 = x3;
-            x3 = __builtin_sqrtf(x3);
-            y6 = y6 + r4;
-            r4 = rsq(y6);
-            r4 = r4 * s.t_eps;
-            x1 = x1 * r4; x2 = x2 * r4; x3 = x3 * r4;
-
-            const u32 tside = side ? sm : 0u;
-            x3 = fxor(x3, f2u(vget(ci.df, (int)mk)) & sm);
-            x3 = fxor(x3, (tside & ci.amask) ^ ci.amask);
-            const u32 u5 = (tside | ci.amask) ^ ci.amask;
-            x1 = fxor(x1, u5);
-            x2 = fxor(x2, u5);
-
-            vset(nw, (int)mi, x1);
-            if (conic != 2) vset(nw, (int)mj, x2);
-            vset(nw, (int)mk, x3);
-            x4 = nw.x; x5 = nw.y; x6 = nw.z;
         }
     }
     loc = nw;
 
     /* axis min/max, 1874-1927: unclipped axes hold -inf / +inf, so the six compares are unconditional
      * (a lane still in `m` has a finite hit point) */
-    m = m && cle(s.min0, x4) && cge(s.max0, x4)
-          && cle(s.min1, x5) && cge(s.max1, x5)
-          && cle(s.min2, x6) && cge(s.max2, x6);
+    m &= LM(cle(s.min0, x4)) & LM(cge(s.max0, x4));
+    m &= LM(cle(s.min1, x5)) & LM(cge(s.max1, x5));
+    m &= LM(cle(s.min2, x6)) & LM(cge(s.max2, x6));
 
     /* custom clipping, 1931-2151: the surface's clipper program */
-    if ((op & QR_OPF_CLIP) && any_lane(m))
+    if ((op & QR_OPF_CLIP) && m != 0)
     {
-        bool c_acc = false;
+        lm_t c_acc = 0;
         V3 cxyz = {0.0f, 0.0f, 0.0f};                   /* the hit in the cached clipper trnode's space */
         u32 cp = s.clip;
         for (;;)
         {
+            cp = __builtin_amdgcn_readfirstlane(cp);
             const u32x2 cc = *(const QR_CONST u32x2 *)(B + cp);
             cp += 16;
-            const u32 cop = cc.x, ctype = QR_CL_TYPE(cop);
-            if (ctype == QR_CL_END) break;
-            if (ctype == QR_CL_ENTER) { c_acc = m; m = (cop & QR_CLF_CDEF) != 0; continue; }
-            if (ctype == QR_CL_LEAVE) { m = !m && c_acc; continue; }
+            const u32 cop = cc.x;
+            if (cop == 0) break;
+            if (cop & (QR_CLT_ENTER | QR_CLT_LEAVE))
+            {
+                if (cop & QR_CLT_ENTER) { c_acc = m; m = (cop & QR_CLF_CDEF) ? ~0ull : 0ull; }
+                else m = ~m & c_acc;
+                continue;
+            }
             const u32 koff = cc.y;
             const u32x4 k0 = *(const QR_CONST u32x4 *)(B + koff);
             const float kp0 = u2f(k0.x), kp1 = u2f(k0.y), kp2 = u2f(k0.z);
-            if (ctype == QR_CL_TRSAME)
+            if (cop & QR_CLT_TRSAME)
             {
                 /* the clipper trnode is the surface's own: its local hit + pos is the hit in that space */
                 cxyz.x = x4 + s.pos0; cxyz.y = x5 + s.pos1; cxyz.z = x6 + s.pos2;
                 continue;
             }
             V3 cv;
-            const u32 cmode = QR_CL_MODE(cop);
-            if (ctype == QR_CL_TRNODE || cmode != QR_OPM_CACHED)
-            {
-                V3 d;
-                d.x = hit.x - kp0; d.y = hit.y - kp1; d.z = hit.z - kp2;
-                if (ctype == QR_CL_TRNODE) { cxyz = xform(B, koff, (cop & QR_CLF_FULLM) != 0, d); continue; }
-                cv = cmode == QR_OPM_OWN ? xform(B, koff, (cop & QR_CLF_FULLM) != 0, d) : d;
-            }
-            else
+            if (cop & QR_CLF_CACHED)
             {
                 cv.x = cxyz.x - kp0; cv.y = cxyz.y - kp1; cv.z = cxyz.z - kp2;
             }
-            float f4;
-            if (ctype == QR_CL_PLANE)
+            else
             {
-                f4 = fxor(vget(cv, (int)QR_CL_AXK(cop)), (cop & QR_CLF_SGNK) ? QR_SMASK : 0u);
+                V3 d;
+                d.x = hit.x - kp0; d.y = hit.y - kp1; d.z = hit.z - kp2;
+                if (cop & QR_CLT_TRNODE) { cxyz = xform(B, koff, (cop & QR_CLF_FULLM) != 0, d); continue; }
+                cv = (cop & QR_CLF_OWN) ? xform(B, koff, (cop & QR_CLF_FULLM) != 0, d) : d;
+            }
+            float f4;
+            if (cop & QR_CLT_PLANE)
+            {
+                f4 = fxor(axis3(cv, (cop & QR_CLF_KX) != 0, (cop & QR_CLF_KY) != 0), (cop & QR_CLF_SGNK) ? QR_SMASK : 0u);
             }
             else
             {
                 const u32x4 k1 = *(const QR_CONST u32x4 *)(B + koff + 48);
                 const float ks0 = u2f(k1.x), ks1 = u2f(k1.y), ks2 = u2f(k1.z), ks3 = u2f(k1.w);
                 float f5, f6;
-                if (ctype == QR_CL_QUADJ)
+                if (cop & QR_CLT_QUADJ)
                 {
                     const u32x4 k2 = *(const QR_CONST u32x4 *)(B + koff + 64);
                     float f1, f2, f3;
@@ -224,7 +241,7 @@ __device__ __forceinline__ bool clip(BaseP B, const SurfS &s, u32 op, const Ray 
                 }
                 f4 = f4 - ks3; f4 = f4 + f5; f4 = f4 + f6;
             }
-            m = m && ((cop & QR_CLF_INNER) ? cge(f4, 0.0f) : cle(f4, 0.0f));
+            m &= (cop & QR_CLF_INNER) ? LM(cge(f4, 0.0f)) : LM(cle(f4, 0.0f));
         }
     }
     return m;
@@ -248,6 +265,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
     /* only the cull uses the ray length: an upper bound is enough there, so the 1-instruction
      * approximate square root (1 ulp) inflated by 2^-20 replaces the IEEE expansion */
     const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    const float dde = dd * 1e-5f;
     float tbd = tbuf * dd;
     u32 pos = __builtin_amdgcn_readfirstlane(head);
 #ifdef QR_STATS
@@ -255,287 +273,295 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
     for (;;)
     {
-        pos = __builtin_amdgcn_readfirstlane(pos);          /* wave-uniform by construction: keep it in an SGPR */
+        pos = __builtin_amdgcn_readfirstlane(pos);      /* wave-uniform by construction; says so to the compiler */
         const u32x8 c = *(const QR_CONST u32x8 *)(B + pos);
         const u32 op = c.s0;
-        const u32 type = QR_OP_TYPE(op);
-        if (type == QR_OP_END) break;
+        if (op == 0) break;
         const u32 srf_off = c.s1;
-        const int si = (int)c.s3;
-        const bool on = resume <= pos;
+        const lm_t on = LM(resume <= pos);
         u32 next = pos + 32;
+        bool full = true;
 #ifdef QR_STATS
-        st_iter++; st_lanes += __popcll(__ballot(on));
+        st_iter++; st_lanes += __popcll(on);
 #endif
         if (op & QR_OPF_CULL)
         {
             /*
              * Wave-level cull (ours, not in the reference): the cell carries a conservative world-space
              * bounding sphere of the surface's visible part; if every ray that is on provably misses it
-             * (perpendicular distance, behind the origin, or beyond the current depth bound) the element
+             * (perpendicular distance / behind the origin, or beyond the current depth bound) the element
              * cannot produce a hit and is skipped without touching its record.  Never applied to a ray's
-             * own surface.  Not reference arithmetic: fused operations are fine here.  The line misses the
-             * sphere iff b^2 < dd * (|oc|^2 - R^2); 1e-5 * |oc|^2 * dd on the left absorbs the rounding of
-             * both sides (a few 1e-7 relative to |oc|^2 * dd), on top of the inflated radius.
+             * own surface.  Not reference arithmetic: fused operations are fine here.  With the origin
+             * outside the sphere (|oc|^2 > 1.01 R^2) the line misses it iff b < 0 or b^2 < dd (|oc|^2 - R^2);
+             * both in one compare with b |b|; 1e-5 |oc|^2 dd on the left absorbs the rounding of both sides
+             * (a few 1e-7 relative to |oc|^2 dd), on top of the inflated radius.
              */
-            const float R = u2f(c.s7);
+            const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
             const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
             const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
             const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-            const float R2 = R * R;
             const float q = oc2 - R2;
-            const bool outside = q > 0.01f * R2;
-            const bool miss = (outside & ((__builtin_fmaf(oc2 * dd, 1e-5f, b * b) < dd * q) | (b < 0.0f)))
-                            | (__builtin_fmaf(-R, dlen, b) > tbd);
-            const bool need = on & !(miss & (si != r.osi));
-            if (!any_lane(need))
-            {
+            const lm_t miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
+                            | LM(__builtin_fmaf(-R, dlen, b) > tbd);
+            const lm_t need = on & ~(miss & LM(srf_off != r.osrf));
+            full = need != 0;
 #ifdef QR_STATS
-                st_skip++;
+            if (!full) st_skip++;
 #endif
-                pos = next;
-                continue;
-            }
         }
 
-        if (type == QR_OP_TRNODE)
+        if (full)
         {
-            /* array element with a transform: diff and ray in its space, cached for the surfaces behind it */
-            if (on)
+            if (op & QR_OPT_TRNODE)
             {
-                const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
-                V3 d;
-                d.x = r.org.x - u2f(p0.x); d.y = r.org.y - u2f(p0.y); d.z = r.org.z - u2f(p0.z);
-                txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
-                trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
-            }
-            pos = next;
-            continue;
-        }
-
-        SurfS s;
-        ld_surf(B, srf_off, s);
-
-        if (on)
-        {
-            /* ---- diff / ray in the surface's space, 1352-1556 ---- */
-            ClipIn ci;
-            ci.dmask = false; ci.amask = 0;
-            const u32 mode = QR_OP_MODE(op);
-            if (mode == QR_OPM_CACHED)
-            {
-                ci.df.x = txyz.x - s.pos0; ci.df.y = txyz.y - s.pos1; ci.df.z = txyz.z - s.pos2;
-                ci.ry = trijk;
+                /* array element with a transform: diff and ray in its space, cached for the surfaces behind it */
+                if (lane_of(on))
+                {
+                    const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
+                    V3 d;
+                    d.x = r.org.x - u2f(p0.x); d.y = r.org.y - u2f(p0.y); d.z = r.org.z - u2f(p0.z);
+                    txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
+                    trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
+                }
             }
             else
             {
-                ci.df.x = r.org.x - s.pos0; ci.df.y = r.org.y - s.pos1; ci.df.z = r.org.z - s.pos2;
-                ci.ry = r.dir;
-                if (mode == QR_OPM_OWN)
-                {
-                    ci.df = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, ci.df);
-                    ci.ry = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
-                }
-            }
-            /* a secondary ray on its own surface starts from the parent's local hit, 1352-1373 */
-            const bool same = si == r.osi;
-            ci.df.x = same ? r.ploc.x : ci.df.x; ci.df.y = same ? r.ploc.y : ci.df.y; ci.df.z = same ? r.ploc.z : ci.df.z;
-            const V3 ry = ci.ry, df = ci.df;
+                SurfS s;
+                ld_surf(B, srf_off, s);
 
-            if (type == QR_OP_BV)
-            {
-                /* AR_ptr 3955-4054 */
-                float x0, x1, x2, x3, x4, x5, x6, x7;
-                x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
-                x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
-                x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
-                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
-                x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                x5 = x5 - s.sci3;
-                x5 = x5 * x1;
-                x3 = x3 * x3;
-                x3 = x3 - x5;
-                if (!cle(0.0f, x3)) resume = c.s2;      /* misses the volume: back at the array's end */
-            }
-            else
-            {
-                /* up to two candidate roots per lane, in the lane's own order */
-                float ct0 = 0.0f, ct1 = 0.0f;
-                int   cs0 = 0, cs1 = 0;
-                bool  cm0 = false, cm1 = false;
-                int   ncand = 0;
-
-                if (type == QR_OP_PLANE)
+                if (lane_of(on))
                 {
-                    /* PL_ptr 4062-4136 */
-                    const u32 mk = QR_OP_AXK(op);
-                    const u32 sg = (op & QR_OPF_SGNK) ? QR_SMASK : 0u;
-                    const float dk = fxor(vget(df, (int)mk), sg ^ QR_SMASK);
-                    const float rk = fxor(vget(ry, (int)mk), sg);
-                    cm0 = !same && cne(0.0f, rk);
-                    /* Pre-test (ours): the hit only survives clip() if t_min < t < t_buf.  With t_min >= 0 a
-                     * quotient of opposite signs cannot, and |dk| >= |rk| * t_buf * (1 + 2^-20) means
-                     * t >= t_buf whatever the rounding of the division; dropping those lanes here changes
-                     * nothing, and when no lane is left the wave skips the IEEE division and clip(). */
+                    /* ---- diff / ray in the surface's space, 1352-1556 ---- */
+                    ClipIn ci;
+                    ci.dmask = 0; ci.amask = 0;
+                    if (op & QR_OPF_CACHED)
                     {
-                        const bool opposite = ((f2u(dk) ^ f2u(rk)) & QR_SMASK) != 0;
-                        const bool beyond = fabs_bits(dk) >= fabs_bits(rk) * (tbuf * 1.000001f);
-                        cm0 = cm0 && !((opposite || beyond) && r.tmin >= 0.0f);
-                    }
-                    if (any_lane(cm0)) { ct0 = dk / rk; ncand = 1; }
-                    cs0 = clt(rk, 0.0f) ? 0 : 1;
-                }
-                else
-                {
-                    float a, b, cq, d;
-                    if (type == QR_OP_QUADRIC)
-                    {
-                        /* QD_ptr 4378-4447 */
-                        float x0, x1, x2, x3, x4, x5, x6, x7;
-                        x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
-                        x7 = x7 - s.scj0; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.scj0; x5 = x5 * x7;
-                        x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
-                        x7 = x7 - s.scj1; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj1; x6 = x6 * x7;
-                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                        x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
-                        x7 = x7 - s.scj2; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj2; x6 = x6 * x7;
-                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                        x5 = x5 - s.sci3;
-                        x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
-                        a = x1; b = x4; cq = x6; d = x3;
+                        ci.df.x = txyz.x - s.pos0; ci.df.y = txyz.y - s.pos1; ci.df.z = txyz.z - s.pos2;
+                        ci.ry = trijk;
                     }
                     else
                     {
-                        /* TP_ptr 4216-4277 */
-                        const u32 mi = QR_OP_AXI(op), mk = QR_OP_AXK(op);
+                        ci.df.x = r.org.x - s.pos0; ci.df.y = r.org.y - s.pos1; ci.df.z = r.org.z - s.pos2;
+                        ci.ry = r.dir;
+                        if (op & QR_OPF_OWN)
+                        {
+                            ci.df = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, ci.df);
+                            ci.ry = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
+                        }
+                    }
+                    /* a secondary ray on its own surface starts from the parent's local hit, 1352-1373 */
+                    const lm_t same = LM(srf_off == r.osrf);
+                    if (same != 0)
+                    {
+                        const bool sl = lane_of(same);
+                        ci.df.x = sl ? r.ploc.x : ci.df.x; ci.df.y = sl ? r.ploc.y : ci.df.y; ci.df.z = sl ? r.ploc.z : ci.df.z;
+                    }
+                    const V3 ry = ci.ry, df = ci.df;
+
+                    if (op & QR_OPT_BV)
+                    {
+                        /* AR_ptr 3955-4054 */
                         float x0, x1, x2, x3, x4, x5, x6, x7;
-                        x1 = vget(ry, (int)mi); x5 = vget(df, (int)mi); x3 = sel3(s.sci0, s.sci1, s.sci2, mi);
-                        x2 = vget(ry, (int)mk); x6 = vget(df, (int)mk); x4 = sel3(s.sci0, s.sci1, s.sci2, mk);
-                        x0 = x5; x7 = x6;
-                        x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
-                        x5 = fabs_bits(x5);
-                        x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
-                        x4 = sel3(s.sci0, s.sci1, s.sci2, mk);
-                        x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
-                        x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
-                        a = x1; b = x3; cq = x0; d = x5;
+                        x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
+                        x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
+                        x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
+                        x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                        x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
+                        x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                        x5 = x5 - s.sci3;
+                        x5 = x5 * x1;
+                        x3 = x3 * x3;
+                        x3 = x3 - x5;
+                        if (!cle(0.0f, x3)) resume = c.s2;      /* misses the volume: back at the array's end */
                     }
-
-                    /* QD_rts 4449-4658 */
-                    const u32 sm = QR_SMASK;
-                    const bool xmask = cle(0.0f, d);
-                    /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
-                    if (any_lane(xmask))
+                    else
                     {
-                        b = fxor(b, sm);
-                        const bool dmask = xmask && clt(d, s.d_eps);
-                        ci.dmask = dmask;
+                        /* up to two candidate roots per lane, in the lane's own order */
+                        float ct0 = 0.0f, ct1 = 0.0f;
+                        int   cs0 = 0, cs1 = 0;
+                        lm_t  cm0 = 0, cm1 = 0;
+                        int   ncand = 0;
 
-                        const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
-                        const float bd = b + sd;
-                        const bool m_pos = cle(0.0f, sd);
-                        /* RT: m_neg = cgt(0, sd) = !m_pos unless sd is NaN (then both selections come out 0) */
-                        const bool m_neg = cgt(0.0f, sd);
-                        const float t2n = u2f((m_neg ? f2u(cq) : 0u) | (m_pos ? f2u(bd) : 0u));
-                        const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(cq) : 0u));
-                        float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
-                        float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
-                        a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
-
-                        const u32 amask = sm & f2u(a);
-                        ci.amask = amask;
-                        if (dmask)
+                        if (op & QR_OPT_PLANE)
                         {
-                            if (ceq(t1n, 0.0f)) t1d = 1.0f;
-                            if (ceq(t2n, 0.0f)) t2d = 1.0f;
-                        }
-                        float t1 = t1n / t1d;
-                        float t2 = t2n / t2d;
-                        const bool t1msk = cne(t1d, 0.0f);
-                        const bool t2msk = cne(t2d, 0.0f);
-                        if (any_lane(dmask))
-                        {
-                            if (dmask)
-                            {
-                                float tdf = t1 - t2;
-                                tdf = fxor(tdf, amask);
-                                const bool f = cle(0.0f, tdf);
-                                tdf = f ? tdf : 0.0f;
-                                float eps = f ? s.t_eps : 0.0f;
-                                eps = eps * t1;
-                                eps = fabs_bits(eps);
-                                tdf = tdf * -0.5f;
-                                tdf = tdf - eps;
-                                tdf = fxor(tdf, amask);
-                                tdf = (t1msk && t2msk) ? tdf : 0.0f;
-                                t1 = t1 + tdf;
-                                t2 = t2 - tdf;
-                            }
-                        }
-
-                        const bool inner_first = xmask && cgt(0.0f, a);
-                        /* CHECK_SIDE 531-540 */
-                        const int f3 = r.oflg & (FLAG_SIDE | FLAG_PASS_THRU);
-                        const bool mo = xmask & t1msk & !(same & ((f3 == 1) | (f3 == 2)));
-                        const bool mi2 = xmask & t2msk & !(same & ((f3 == 0) | (f3 == 3)));
-                        ncand = 2;
-                        ct0 = inner_first ? t2 : t1; ct1 = inner_first ? t1 : t2;
-                        cs0 = inner_first ? 1 : 0;   cs1 = inner_first ? 0 : 1;
-                        cm0 = inner_first ? mi2 : mo; cm1 = inner_first ? mo : mi2;
-                    }
-                }
-
-                bool done = false;
-#pragma nounroll
-                for (int p = 0; p < ncand; p++)
-                {
-                    const float t = p == 0 ? ct0 : ct1;
-                    const int side = p == 0 ? cs0 : cs1;
-                    bool m = (p == 0 ? cm0 : cm1) && !done;
-                    if (!any_lane(m)) continue;
-                    V3 loc;
-                    m = clip(B, s, op, r, tbuf, ci, t, side, m, loc);
-                    if (m)
-                    {
-                        done = true;
-                        if (SHADOW)
-                        {
-                            /* CHECK_SHAD 549-589: by the surface's material (static class in the opcode) */
-                            const u32 sc_ = QR_OP_SHAD(op);
-                            bool casts = sc_ == 0;
-                            if (sc_ == 2)
-                            {
-                                const QR_CONST DSurf *P = (const QR_CONST DSurf *)(B + srf_off);
-                                const int props = side ? P->props1 : P->props0;
-                                casts = !((props & QR_PROP_LIGHT) || ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT)));
-                            }
-                            if (casts) resume = 0xFFFFFFFFu;        /* occluded: the ray leaves the walk */
+                            /* PL_ptr 4062-4136 */
+                            const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
+                            const u32 sg = (op & QR_OPF_SGNK) ? QR_SMASK : 0u;
+                            const float dk = fxor(axis3(df, kx, ky), sg ^ QR_SMASK);
+                            const float rk = fxor(axis3(ry, kx, ky), sg);
+                            /* Pre-test (ours): the hit only survives clip() if t_min < t < t_buf.  With t_min >= 0 a
+                             * quotient of opposite signs cannot, and |dk| >= |rk| * t_buf * (1 + 2^-20) means
+                             * t >= t_buf whatever the rounding of the division; dropping those lanes here changes
+                             * nothing, and when no lane is left the wave skips the IEEE division and clip(). */
+                            const lm_t opposite = LM(((f2u(dk) ^ f2u(rk)) & QR_SMASK) != 0);
+                            const lm_t beyond = LM(fabs_bits(dk) >= fabs_bits(rk) * (tbuf * 1.000001f));
+                            cm0 = LM(cne(0.0f, rk)) & ~same & ~((opposite | beyond) & LM(r.tmin >= 0.0f));
+                            if (cm0 != 0) { ct0 = dk / rk; ncand = 1; }
+                            cs0 = clt(rk, 0.0f) ? 0 : 1;
                         }
                         else
                         {
-                            /* PAINT_FRAG 653-662: depth write; shading is deferred */
-                            tbuf = t; tbd = t * dd;
-                            h.t = t; h.si = si; h.side = side;
-                            h.loc = loc;
+                            float a, b, cq, d;
+                            if (op & QR_OPT_QUADRIC)
+                            {
+                                /* QD_ptr 4378-4447 */
+                                float x0, x1, x2, x3, x4, x5, x6, x7;
+                                x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
+                                x7 = x7 - s.scj0; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.scj0; x5 = x5 * x7;
+                                x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
+                                x7 = x7 - s.scj1; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj1; x6 = x6 * x7;
+                                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                                x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
+                                x7 = x7 - s.scj2; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj2; x6 = x6 * x7;
+                                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                                x5 = x5 - s.sci3;
+                                x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
+                                a = x1; b = x4; cq = x6; d = x3;
+                            }
+                            else
+                            {
+                                /* TP_ptr 4216-4277 */
+                                const bool ix = (op & QR_OPF_IX) != 0, iy = (op & QR_OPF_IY) != 0;
+                                const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
+                                const V3 sc3 = {s.sci0, s.sci1, s.sci2};
+                                float x0, x1, x2, x3, x4, x5, x6, x7;
+                                x1 = axis3(ry, ix, iy); x5 = axis3(df, ix, iy); x3 = axis3(sc3, ix, iy);
+                                x2 = axis3(ry, kx, ky); x6 = axis3(df, kx, ky); x4 = axis3(sc3, kx, ky);
+                                x0 = x5; x7 = x6;
+                                x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
+                                x5 = fabs_bits(x5);
+                                x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
+                                x4 = axis3(sc3, kx, ky);
+                                x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
+                                x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
+                                a = x1; b = x3; cq = x0; d = x5;
+                            }
+
+                            /* QD_rts 4449-4658 */
+                            const u32 sm = QR_SMASK;
+                            const lm_t xmask = LM(cle(0.0f, d));
+                            /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
+                            if (xmask != 0)
+                            {
+                                b = fxor(b, sm);
+                                const lm_t dmask = xmask & LM(clt(d, s.d_eps));
+                                ci.dmask = dmask;
+
+                                const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
+                                const float bd = b + sd;
+                                const bool m_pos = cle(0.0f, sd);
+                                /* m_neg = cgt(0, sd) = !m_pos unless sd is NaN (then both selections come out 0) */
+                                const bool m_neg = cgt(0.0f, sd);
+                                const float t2n = u2f((m_neg ? f2u(cq) : 0u) | (m_pos ? f2u(bd) : 0u));
+                                const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(cq) : 0u));
+                                float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
+                                float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                                a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
+
+                                const u32 amask = sm & f2u(a);
+                                ci.amask = amask;
+                                if (dmask != 0)
+                                {
+                                    if (lane_of(dmask))
+                                    {
+                                        if (ceq(t1n, 0.0f)) t1d = 1.0f;
+                                        if (ceq(t2n, 0.0f)) t2d = 1.0f;
+                                    }
+                                }
+                                float t1 = t1n / t1d;
+                                float t2 = t2n / t2d;
+                                const lm_t t1msk = LM(cne(t1d, 0.0f));
+                                const lm_t t2msk = LM(cne(t2d, 0.0f));
+                                if (dmask != 0)
+                                {
+                                    if (lane_of(dmask))
+                                    {
+                                        float tdf = t1 - t2;
+                                        tdf = fxor(tdf, amask);
+                                        const bool f = cle(0.0f, tdf);
+                                        tdf = f ? tdf : 0.0f;
+                                        float eps = f ? s.t_eps : 0.0f;
+                                        eps = eps * t1;
+                                        eps = fabs_bits(eps);
+                                        tdf = tdf * -0.5f;
+                                        tdf = tdf - eps;
+                                        tdf = fxor(tdf, amask);
+                                        tdf = lane_of(t1msk & t2msk) ? tdf : 0.0f;
+                                        t1 = t1 + tdf;
+                                        t2 = t2 - tdf;
+                                    }
+                                }
+
+                                const bool inner_first = cgt(0.0f, a);      /* only read where xmask holds */
+                                lm_t mo = xmask & t1msk, mi2 = xmask & t2msk;
+                                if (same != 0)
+                                {
+                                    /* CHECK_SIDE 531-540: on its own surface a ray that left through the outer side
+                                     * (flags 0: reflected off it, 3: passed through from inside) skips the inner root,
+                                     * one that left through the inner side (1, 2) the outer root */
+                                    const lm_t so = LM(((r.oflg ^ (r.oflg >> 1)) & 1) != 0);
+                                    mo &= ~(same & so);
+                                    mi2 &= ~(same & ~so);
+                                }
+                                ncand = 2;
+                                ct0 = inner_first ? t2 : t1; ct1 = inner_first ? t1 : t2;
+                                cs0 = inner_first ? 1 : 0;   cs1 = inner_first ? 0 : 1;
+                                const lm_t inf = LM(inner_first);
+                                cm0 = (inf & mi2) | (~inf & mo); cm1 = (inf & mo) | (~inf & mi2);
+                            }
+                        }
+
+                        lm_t done = 0;
+#pragma nounroll
+                        for (int p = 0; p < ncand; p++)
+                        {
+                            const float t = p == 0 ? ct0 : ct1;
+                            const int side = p == 0 ? cs0 : cs1;
+                            lm_t m = (p == 0 ? cm0 : cm1) & ~done;
+                            if (m == 0) continue;
+                            V3 loc;
+                            m = clip(B, s, op, r, tbuf, ci, t, side, m, loc);
+                            done |= m;
+                            if (lane_of(m))
+                            {
+                                if (SHADOW)
+                                {
+                                    /* CHECK_SHAD 549-589: by the surface's material (static class in the opcode) */
+                                    bool casts = (op & QR_OPF_NOSHAD) == 0;
+                                    if (op & QR_OPF_SIDESHAD)
+                                    {
+                                        const QR_CONST DSurf *P = (const QR_CONST DSurf *)(B + srf_off);
+                                        const int props = side ? P->props1 : P->props0;
+                                        casts = !((props & QR_PROP_LIGHT) || ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT)));
+                                    }
+                                    if (casts) resume = 0xFFFFFFFFu;        /* occluded: the ray leaves the walk */
+                                }
+                                else
+                                {
+                                    /* PAINT_FRAG 653-662: depth write; shading is deferred */
+                                    tbuf = t; tbd = t * dd;
+                                    h.t = t; h.srf = srf_off; h.side = side;
+                                    h.loc = loc;
+                                }
+                            }
                         }
                     }
                 }
-            }
-        }
 
-        if (type == QR_OP_BV)
-        {
-            /* the reference jumps a whole packet behind an array whose bounding volume no lane hits
-             * (tracer.cpp:4040-4054); rays that were off already wait for the end of an enclosing array,
-             * which lies at or behind this array's end (arrays nest, qr_compile.cpp) */
-            if (!any_lane(resume <= pos)) next = c.s2;
-        }
-        else if (SHADOW)
-        {
-            if (!any_lane(resume != 0xFFFFFFFFu)) break;       /* every ray of the group is occluded */
+                if (op & QR_OPT_BV)
+                {
+                    /* the reference jumps a whole packet behind an array whose bounding volume no lane hits
+                     * (tracer.cpp:4040-4054); rays that were off already wait for the end of an enclosing array,
+                     * which lies at or behind this array's end (arrays nest, qr_compile.cpp) */
+                    if (LM(resume <= pos) == 0) next = c.s2;
+                }
+                else if (SHADOW)
+                {
+                    if (LM(resume != 0xFFFFFFFFu) == 0) break;      /* every ray of the group is occluded */
+                }
+            }
         }
         pos = next;
     }
@@ -543,7 +569,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #ifdef QR_STATS
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
     {
-        const int b = SHADOW ? 0 : (r.osi == QR_NULL ? 3 : 6);
+        const int b = SHADOW ? 0 : (r.osrf == 0 ? 3 : 6);
         atomicAdd(&stats[b + 0], 1ull);
         atomicAdd(&stats[b + 1], st_iter);
         atomicAdd(&stats[b + 2], st_lanes);
@@ -562,23 +588,22 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, const Ray &r, Hit
 #endif
                                          )
 {
-    h.t = r.tmax; h.si = QR_NULL; h.side = 0; h.loc = {0, 0, 0};
+    h.t = r.tmax; h.srf = 0; h.side = 0; h.loc = {0, 0, 0};
     occluded = false;
-    active = active && r.list != 0;
-    unsigned long long pending = __ballot(active);
+    lm_t pending = LM(active && r.list != 0);
     while (pending != 0)
     {
         const int leader = __ffsll((long long)pending) - 1;
-        const u32 head = (u32)__shfl((int)r.list, leader);
-        const bool mine = active && r.list == head;
-        pending &= ~__ballot(mine);
-        if (mine)
+        const u32 head = (u32)__builtin_amdgcn_readlane((int)r.list, leader);
+        const lm_t mine = pending & LM(r.list == head);
+        pending &= ~mine;
+        if (lane_of(mine))
         {
             walk_list<SHADOW>(B, head, r, h, occluded
 #ifdef QR_STATS
-                                       , stats
+                              , stats
 #endif
-                                       );
+                              );
         }
     }
 }
