@@ -82,6 +82,34 @@ __device__ __forceinline__ float sel3(float a, float b, float c, u32 i) { return
 /* component by one-hot axis flags (x, y, else z): two v_cndmask on scalar conditions */
 __device__ __forceinline__ float axis3(const V3 &v, bool is_x, bool is_y) { return is_x ? v.x : (is_y ? v.y : v.z); }
 
+/*
+ * The eight compares of CC_clp that only narrow the mask (depth, near, axis min/max) as ONE chain of
+ * v_cmpx: each compare ANDs itself into EXEC, so a condition costs one instruction instead of a compare
+ * plus an s_and.  EXEC is saved and restored inside the block; predicates as in the reference
+ * (cgt = NLE, cge = NLT: true on NaN; cle / clt: false on NaN).
+ */
+__device__ __forceinline__ lm_t clip_box(lm_t m, float tbuf, float tmin, float t, float x4, float x5, float x6, const SurfS &s)
+{
+    lm_t out, sv;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, %2\n\t"
+                 "v_cmpx_nle_f32 vcc, %3, %5\n\t"       /* cgt(tbuf, t)  */
+                 "v_cmpx_lt_f32 vcc, %4, %5\n\t"        /* clt(tmin, t)  */
+                 "v_cmpx_le_f32 vcc, %9, %6\n\t"        /* cle(min0, x4) */
+                 "v_cmpx_nlt_f32 vcc, %12, %6\n\t"      /* cge(max0, x4) */
+                 "v_cmpx_le_f32 vcc, %10, %7\n\t"
+                 "v_cmpx_nlt_f32 vcc, %13, %7\n\t"
+                 "v_cmpx_le_f32 vcc, %11, %8\n\t"
+                 "v_cmpx_nlt_f32 vcc, %14, %8\n\t"
+                 "s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=s"(out), "=&s"(sv)
+                 : "s"(m), "v"(tbuf), "v"(tmin), "v"(t), "v"(x4), "v"(x5), "v"(x6),
+                   "s"(s.min0), "s"(s.min1), "s"(s.min2), "s"(s.max0), "s"(s.max1), "s"(s.max2)
+                 : "vcc");
+    return out;
+}
+
 /* ------------------------------------------------------------------------ */
 /* CC_clp, tracer.cpp:1597-2160.  Returns the lanes of `m` whose hit at `t`  */
 /* survives; `loc` is the local hit (ctx_NEW_* of the surface's space).      */
@@ -89,10 +117,12 @@ __device__ __forceinline__ float axis3(const V3 &v, bool is_x, bool is_y) { retu
 __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
                                      const ClipIn &ci, float t, int side, lm_t m, V3 &loc)
 {
+    /* the opcode is re-read through an opaque copy: otherwise everything that only depends on it (the whole
+     * axis decode of the conic fix, every flag as a 64-bit mask) is hoisted in front of the candidate loop and
+     * paid by every cell */
+    asm volatile("" : "+s"(op));
     float x4, x5, x6;
     V3 hit;
-
-    m &= LM(cgt(tbuf, t)) & LM(clt(r.tmin, t));
 
     x4 = r.dir.x * t; x4 = x4 + r.org.x; hit.x = x4;
     x5 = r.dir.y * t; x5 = x5 + r.org.y; hit.y = x5;
@@ -116,7 +146,8 @@ __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray 
     /* conic singularity solver, 1706-1856 */
     if (op & QR_OPF_CONIC)
     {
-        const u32 fl = s.flags;
+        u32 fl = s.flags;
+        asm volatile("" : "+s"(fl));
         const u32 conic = DF_CONIC(fl);
         const u32 mi = DF_MAP(fl, 0), mj = DF_MAP(fl, 1), mk = DF_MAP(fl, 2);
         float x0, x1, x2, x3;
@@ -166,11 +197,9 @@ __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray 
     }
     loc = nw;
 
-    /* axis min/max, 1874-1927: unclipped axes hold -inf / +inf, so the six compares are unconditional
-     * (a lane still in `m` has a finite hit point) */
-    m &= LM(cle(s.min0, x4)) & LM(cge(s.max0, x4));
-    m &= LM(cle(s.min1, x5)) & LM(cge(s.max1, x5));
-    m &= LM(cle(s.min2, x6)) & LM(cge(s.max2, x6));
+    /* depth + near test (1600-1640) and axis min/max (1874-1927): unclipped axes hold -inf / +inf, so the six
+     * compares are unconditional (a lane still in `m` has a finite hit point) */
+    m = clip_box(m, tbuf, r.tmin, t, x4, x5, x6, s);
 
     /* custom clipping, 1931-2151: the surface's clipper program */
     if ((op & QR_OPF_CLIP) && m != 0)
@@ -529,8 +558,10 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
                                 if (SHADOW)
                                 {
                                     /* CHECK_SHAD 549-589: by the surface's material (static class in the opcode) */
-                                    bool casts = (op & QR_OPF_NOSHAD) == 0;
-                                    if (op & QR_OPF_SIDESHAD)
+                                    u32 opl = op;
+                                    asm volatile("" : "+s"(opl));
+                                    bool casts = (opl & QR_OPF_NOSHAD) == 0;
+                                    if (opl & QR_OPF_SIDESHAD)
                                     {
                                         const QR_CONST DSurf *P = (const QR_CONST DSurf *)(B + srf_off);
                                         const int props = side ? P->props1 : P->props0;
