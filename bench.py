@@ -71,11 +71,26 @@ def algorithmic_work(snap):
         return None
 
 
-def measured_valu(workload):
-    """SQ counter summary of the committed rocprofv3 --pmc passes (profiles/valu.json)."""
+def golden_hash(snap):
+    """Reference frame fingerprint of a golden snapshot (tests/golden/manifest.json), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
-            return json.load(f).get(workload)
+        with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+            return int(json.load(f)[snap]["hash"], 16)
+    except Exception:
+        return None
+
+
+def committed_counters(workload):
+    """Hardware-counter figures of the dominant kernel that a bench run cannot take itself (rocprofv3 --pmc
+    passes, tools/gpu_profile_round.sh): per-launch SQ instruction counts and HBM bytes.  They come from
+    profiles/counters.json and are tagged as NOT measured in this run, with the profile they came from."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+            c = json.load(f).get(workload)
+        if c is not None:
+            c = dict(c)
+            c["measured_in_this_run"] = False
+        return c
     except Exception:
         return None
 
@@ -103,26 +118,22 @@ def load_sharding():
     return mod
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); None if not measured."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
-
-
-def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
+def cpu_baseline(workload, rays_per_frame, gpu_frame=None, frames_budget_s=12.0):
     """Time the CPU path on this box's host cores (rank 0, N=1 only): the unmodified reference
     (oracle/_ref/qr_ref, kind "reference") when its prebuilt binary travelled with the repo,
-    else our OpenMP restatement (kind "port")."""
-    cores = min(os.cpu_count() or 1, 16)
+    else our OpenMP restatement (kind "port").  16 threads (where the reference's scanline interleave is
+    fastest), with an all-cores and a single-thread figure beside it; `host_cores` is the box's core count."""
+    total = os.cpu_count() or 1
+    try:
+        total = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(total, 16)     # the reference's row interleave is fastest around 16 threads; an all-cores figure goes beside it
     ref = os.path.join(ROOT, "oracle", "_ref", "qr_ref")
     snap, ref_args, _ = WORKLOADS[workload]
     if ref_args is None:
-        # no reference scene: the oracle port on a horizontal band of the frame, rays counted by the oracle
+        # no reference scene: the oracle port on a horizontal band of the frame, rays and fp32 operations counted
+        # by the oracle; the band's pixels are also the correctness check of the GPU frame for this workload
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import qr_oracle
         blob = load_blob(snap)
@@ -130,11 +141,16 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
         rows = 8
         t0 = time.time(); _, _, c = qr_oracle.render(blob, threads=cores, rows=(h // 2, h // 2 + rows), deferred=True); dt = time.time() - t0
         rows = int(max(8, min(h // 2, rows * frames_budget_s / max(dt, 1e-3)))) // 8 * 8
-        t0 = time.time(); _, _, c = qr_oracle.render(blob, threads=cores, rows=(h // 2 - rows // 2, h // 2 - rows // 2 + rows), deferred=True); dt = time.time() - t0
+        r0 = h // 2 - rows // 2
+        t0 = time.time(); fr, _, c = qr_oracle.render(blob, threads=cores, rows=(r0, r0 + rows), deferred=True); dt = time.time() - t0
         rays = c["primary"] + c["shadow"] + c["reflect"] + c["refract"]
-        return dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
-                    sample=f"{rows} rows around the middle of the frame with oracle/qr_oracle.c (scalar C + OpenMP, {cores} threads): "
-                           f"{rays} rays in {dt:.2f} s")
+        res = dict(value=rays / dt / 1e6, unit="Mrays/s", cores=cores, host_cores=total, kind="port",
+                   sample=f"{rows} rows around the middle of the frame with oracle/qr_oracle.c (scalar C + OpenMP, {cores} threads): "
+                          f"{rays} rays in {dt:.2f} s",
+                   band=dict(rows=[r0, r0 + rows], rays=rays, flops=c["flops"]))
+        if gpu_frame is not None:
+            res["band"]["gpu_pixels_differ"] = int((gpu_frame[r0:r0 + rows] != fr[r0:r0 + rows]).sum())
+        return res
     if os.path.exists(ref):
         try:
             import tempfile
@@ -147,22 +163,27 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
                 line = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0].split()
                 head = out.stdout.splitlines()[0]
                 return float(line[line.index("median_ms") + 1]), head
-            ms, _ = run(3, cores)               # calibrate, then fill the time budget
-            n = int(max(5, min(3000, frames_budget_s * 1000.0 / max(ms, 0.01))))
-            ms, head = run(n, cores)
+
+            def timed(threads, budget_s, cap):
+                ms, _ = run(3, threads)             # calibrate, then fill the time budget
+                n = int(max(5, min(cap, budget_s * 1000.0 / max(ms, 0.01))))
+                ms, head = run(n, threads)
+                return ms, n, head
+            ms, n, head = timed(cores, frames_budget_s, 3000)
             simd = head.split("simd ")[1].split()[0] if "simd " in head else "auto"
-            res = dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="reference",
+            res = dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, host_cores=total, kind="reference",
                        sample=f"{n} frames of the same workload through the unmodified reference's rt_Scene::render "
-                              f"(update phases included, SIMD target {simd}, {cores} threads), median {ms:.3f} ms/frame")
-            try:
-                # the same binary on ONE host thread (the reference's default RooT/core_test configuration), ~5 s
-                ms1, _ = run(3, 1)
-                n1 = int(max(5, min(1000, 5000.0 / max(ms1, 0.01))))
-                ms1, _ = run(n1, 1)
-                res["single_thread"] = dict(value=rays_per_frame / ms1 / 1e3, unit="Mrays/s", cores=1,
-                                            sample=f"{n1} frames, median {ms1:.3f} ms/frame")
-            except Exception as e:
-                print(f"single-thread baseline failed: {e}", file=sys.stderr)
+                              f"(update phases included, SIMD target {simd}, {cores} threads on a box with {total} host cores), "
+                              f"median {ms:.3f} ms/frame")
+            for label, th, budget in (("all_cores", total, 6.0), ("single_thread", 1, 5.0)):
+                if th == cores:
+                    continue
+                try:
+                    ms1, n1, _ = timed(th, budget, 1000)
+                    res[label] = dict(value=rays_per_frame / ms1 / 1e3, unit="Mrays/s", cores=th,
+                                      sample=f"{n1} frames, median {ms1:.3f} ms/frame")
+                except Exception as e:
+                    print(f"{label} baseline failed: {e}", file=sys.stderr)
             return res
         except Exception as e:  # fall through to the port
             print(f"reference baseline failed: {e}", file=sys.stderr)
@@ -176,7 +197,7 @@ def cpu_baseline(workload, rays_per_frame, frames_budget_s=15.0):
         t0 = time.time(); qr_oracle.render(blob, threads=cores); ts.append(time.time() - t0)
     ts.sort()
     ms = ts[len(ts) // 2] * 1e3
-    return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, kind="port",
+    return dict(value=rays_per_frame / ms / 1e3, unit="Mrays/s", cores=cores, host_cores=total, kind="port",
                 sample=f"{n} frames of the same workload with oracle/qr_oracle.c (scalar C + OpenMP), median {ms:.3f} ms/frame")
 
 
@@ -222,6 +243,22 @@ def main():
     _, rc = scn.render_count()
     rays_per_frame = rc.total()
     samples_per_frame = rc.primary
+
+    # CORRECTNESS GATE, before anything is timed: the frame of the timed kernel variant must have the
+    # fingerprint of the reference's frame (tests/golden/manifest.json).  No timing is reported otherwise.
+    want_hash = golden_hash(snap)
+    gate = scn.new_frame()
+    scn.render(gate)
+    torch.cuda.synchronize()
+    frame_check = {"kind": "none: no reference frame exists for this workload", "ok": None}
+    if want_hash is not None:
+        got = qr.frame_hash(gate)
+        frame_check = {"kind": "FNV-1a-64 of the whole frame == the reference's (tests/golden/manifest.json)",
+                       "hash": f"{got:016x}", "ok": got == want_hash}
+        if got != want_hash:
+            print(json.dumps({"error": "rendered frame differs from the reference frame", "workload": args.workload,
+                              "hash": f"{got:016x}", "expected": f"{want_hash:016x}"}), flush=True)
+            raise SystemExit(2)
 
     ex = sharding.FrameExchange(H, W, N, rank)
     # --inflight steps are in flight (one render target set and one HIP stream each), so the long recursion
@@ -288,17 +325,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # correctness gate inside the bench: the assembled frame must equal a whole-frame render
+    # the frames the TIMED steps produced are checked too: every buffer still in flight at the end
     ok = True
     if N > 1:
-        whole = scn.new_frame()
-        scn.set_rows(0, H, 0, 1)
-        scn.render(whole)
-        torch.cuda.synchronize()
-        ok = bool((whole == finals[(args.steps - 1) % B]).all().item())
+        # the assembled frame must equal a whole-frame render of this rank (which passed the gate above)
+        ok = bool((gate == finals[(args.steps - 1) % B]).all().item())
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
+    else:
+        for b in range(min(B, args.steps + args.warmup)):
+            ok = ok and bool((gate == frames[b][0]).all().item())
+    frame_check["timed_frames_match"] = ok
+    if not ok:
+        if rank == 0:
+            print(json.dumps({"error": "a frame produced inside the timed region differs from the checked frame",
+                              "workload": args.workload}), flush=True)
+        raise SystemExit(3)
+    collective = None
+    if N > 1:
+        devs = [None] * N
+        dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}")
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": devs,
+                      "pattern": "grouped point-to-point all-to-all of row blocks, one per step group (sharding.py)"}
 
     # dominant-kernel duration: HIP events recorded on the launch stream around full-frame launches
     scn.set_rows(0, H, 0, 1)
@@ -309,30 +358,43 @@ def main():
         frames_done = args.steps * N
         total_rays = rays_per_frame * frames_done
         value = total_rays / dt / 1e6
-        bw = {0: 32, 1: 16, 2: 8}[scn.info.fsaa]
-        n_wg = ((W + bw - 1) // bw) * n_groups
-        # bytes_alg = 4*W*H (frame write) + n_workgroups * scene_bytes with one workgroup per
-        # 32x8 reference tile (the kernel now runs one wave per workgroup; the tile count is kept as the unit so
-        # that the figure does not grow with the launch shape), scene_bytes = the
-        # surface + material + light records one tile's rays need (128 B device surface records + 32 B shading
-        # records, 128 B materials, 64 B lights)
-        scene_bytes = scn.info.n_srf * (128 + 32) + scn.info.n_mat * 128 + scn.info.n_lgt * 64
-        alg_bytes = 4 * W * H + n_wg * scene_bytes
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(args.workload),
-                        kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms,
-                        algorithmic_bytes_per_launch=alg_bytes,
-                        note="the path is scalar-per-ray fp32 VALU work: the HBM fraction is small by construction "
-                             "(4 B/pixel out + one scene read per workgroup), see DESIGN.md 'Roofline'")
+        cpu = None
+        if N == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload, rays_per_frame, gpu_frame=gate.cpu().numpy().view("uint32"))
+            band = cpu.get("band") if cpu else None
+            if band is not None and "gpu_pixels_differ" in band:
+                frame_check = {"kind": f"rows {band['rows'][0]}..{band['rows'][1]} equal the oracle's pixels (no reference frame exists for a synthetic scene)",
+                               "ok": band["gpu_pixels_differ"] == 0, "timed_frames_match": ok}
+                if band["gpu_pixels_differ"] != 0:
+                    print(json.dumps({"error": "rendered rows differ from the oracle", "workload": args.workload}), flush=True)
+                    raise SystemExit(2)
+        # Which roofline: the path is scalar-per-ray fp32 VALU work -> the VECTOR ALU is the primary
+        # bound.  achieved = algorithmic fp32 operations per launch (SURVEY 8(d) weights, counted by the oracle:
+        # tests/golden/work.json, div and sqrt = 1) / the kernel's mean launch duration measured here with HIP events;
+        # peak = the FMA-counting fp32 vector peak (bit-exactness forbids contraction, so half of it is the most
+        # un-fused arithmetic can reach).
         work = algorithmic_work(snap)
+        flops, flops_src = None, None
         if work is not None and work["rays"] == rays_per_frame:
-            tf = work["flops"] / (avg_ms * 1e-3) / 1e12
-            # the second, meaningful bound: fp32 vector ALU.  Algorithmic fp32 operations
-            # (div, sqrt = 1) over the kernel time against the FMA-counting vector peak; bit-exactness
-            # forbids contraction, so half of that peak is the most un-fused arithmetic can reach.
-            roofline["valu"] = dict(flops_per_launch=work["flops"], achieved=tf, peak=VALU_PEAK_TFLOPS,
-                                    unit="TFLOP/s", frac=tf / VALU_PEAK_TFLOPS, counters=measured_valu(args.workload))
+            flops, flops_src = work["flops"], "oracle count of the whole frame, tests/golden/work.json"
+        elif cpu is not None and cpu.get("band"):
+            flops = int(cpu["band"]["flops"] / max(1, cpu["band"]["rays"]) * rays_per_frame)
+            flops_src = "oracle count on the cpu_baseline band, scaled by rays"
+        counters = committed_counters(args.workload)
+        roofline = dict(bound="valu", achieved=None, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
+                        traffic=(counters or {}).get("hbm_bytes_per_launch"),
+                        kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms)
+        if flops is not None:
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            roofline.update(achieved=tf, frac=tf / VALU_PEAK_TFLOPS, flops_per_launch=flops, flops_source=flops_src)
+        # the HBM leg, for the record (deliberate correction of SURVEY 8(d): the kernel reads the scene through the
+        # scalar cache, not once per workgroup, so the algorithmic bytes are one frame write + one scene read)
+        alg_bytes = 4 * W * H + int(scn.info.device_bytes)
+        gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline["hbm"] = dict(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                               algorithmic_bytes_per_launch=alg_bytes)
+        if counters is not None:
+            roofline["counters"] = counters
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -343,13 +405,12 @@ def main():
                        "rays": rc.as_dict(),
                        "parallelism": f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
-                       "assembled_frame_matches": ok},
+                       "frame_check": frame_check, "assembled_frame_matches": ok},
             "roofline": roofline,
+            "cpu_baseline": cpu,
         }
-        if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, rays_per_frame)
-        else:
-            out["cpu_baseline"] = None
+        if collective is not None:
+            out["collective"] = collective
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -202,6 +202,13 @@ int qr_render_timed(qr_device_scene *scn, void *frame_dev, void *stream,
 /* 3. Misc                                                                   */
 /* ------------------------------------------------------------------------ */
 
+/*
+ * Fingerprint of a frame: FNV-1a-64 over (pixel & 0xFFFFFF) as 4 little-endian bytes, row-major, compact
+ * stride.  The same definition tests/golden/manifest.json uses for the reference's frames, so a caller
+ * (bench.py) can check a rendered frame against the reference without any test code.
+ */
+uint64_t qr_frame_hash(const uint32_t *frame_host, uint64_t n_pixels);
+
 const char *qr_last_error(void);
 const char *qr_version(void);
 int qr_device_count(void);

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
-    "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
+    "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
 ]
 
 
@@ -84,6 +84,8 @@ def lib():
     L.qr_scene_upload_ex.argtypes = [vp, cu64, ci, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.qr_scene_destroy.argtypes = [vp]
     L.qr_program_stats.argtypes = [vp, cu64, ctypes.POINTER(ProgramInfo)]
+    L.qr_frame_hash.argtypes = [vp, cu64]
+    L.qr_frame_hash.restype = cu64
     L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
     L.qr_scene_set_depth.argtypes = [vp, ci]
     L.qr_scene_set_rows.argtypes = [vp, ci, ci, ci, ci]
@@ -108,6 +110,15 @@ def read_snapshot(path):
     with open(path, "rb") as f:
         raw = f.read()
     return gzip.decompress(raw) if path.endswith(".gz") else raw
+
+
+def frame_hash(frame):
+    """FNV-1a-64 fingerprint of a frame (numpy uint32 array or CUDA int32 tensor), as in tests/golden/manifest.json."""
+    import numpy as np
+    if hasattr(frame, "cpu"):
+        frame = frame.cpu().numpy()
+    f = np.ascontiguousarray(frame).view(np.uint32)
+    return int(lib().qr_frame_hash(f.ctypes.data_as(ctypes.c_void_p), f.size))
 
 
 def program_stats(blob):

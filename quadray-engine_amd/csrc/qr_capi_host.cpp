@@ -39,6 +39,20 @@ extern "C" int qr_flatten(const void *s_inf, const qr_abi_desc *abi, void **blob
 
 extern "C" void qr_free(void *blob) { free(blob); }
 
+/* FNV-1a 64 over (pixel & 0xFFFFFF) as 4 little-endian bytes, row-major: the frame fingerprint
+ * tests/golden/manifest.json records for every reference frame */
+extern "C" uint64_t qr_frame_hash(const uint32_t *frame, uint64_t n_pixels)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    if (frame == nullptr) return h;
+    for (uint64_t i = 0; i < n_pixels; i++)
+    {
+        const uint32_t v = frame[i] & 0x00FFFFFFu;
+        for (int b = 0; b < 4; b++) { h ^= (v >> (8 * b)) & 0xFFu; h *= 0x100000001b3ull; }
+    }
+    return h;
+}
+
 extern "C" int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, const char *path)
 {
     if (path == nullptr) return qr_fail(QR_ERR_ARG, "null path");

@@ -92,6 +92,89 @@ def test_upload_rejects_oversized_frame_and_broken_lists(qr):
     assert rc == -1 and "cyclic" in msg, msg
 
 
+def _patch_frame(blob, **fields):
+    """A copy of the snapshot with int32 fields of its qr_frame record replaced (include/qr_scene.h)."""
+    import struct
+    idx = dict(depth=29, fsaa=30, frm_w=31, frm_h=32, tile_w=34, tile_h=35, tls_row=36, tls_col=37, index=39, thnum=40)
+    b = bytearray(blob)
+    off_frame = struct.unpack_from("<I", b, 4 * 10)[0]
+    for k, v in fields.items():
+        struct.pack_into("<i", b, off_frame + 4 * idx[k], v)
+    return bytes(b)
+
+
+@pytest.mark.parametrize("fields,what", [
+    (dict(depth=-1), "depth"),
+    (dict(tls_row=-5, tls_col=-3), "tile grid"),          # product still equals n_tiles = 15
+    (dict(tls_row=3, tls_col=5), "cover"),                # 15 tiles of 32x8 cannot cover 160x120
+    (dict(index=4, thnum=4), "index"),
+    (dict(index=-1), "index"),
+    (dict(tile_w=0), "frame parameters"),
+])
+def test_upload_rejects_bad_frame_records(qr, fields, what):
+    """Every frame-record value the kernel indexes with is checked on the host: a negative recursion depth would
+    walk the per-lane frame stack out of bounds, a tile grid that does not cover the frame the tile array."""
+    blob = load_blob("demo01_160")
+    n_tiles = qr.program_stats(blob).n_sched      # well-formed original compiles
+    assert n_tiles > 0
+    if "tls_row" in fields and fields["tls_row"] > 0:
+        import struct
+        b = bytearray(_patch_frame(blob, **fields))
+        struct.pack_into("<I", b, 4 * 8, fields["tls_row"] * fields["tls_col"])     # keep n_tiles consistent
+        bad = bytes(b)
+    else:
+        bad = _patch_frame(blob, **fields)
+    with pytest.raises(qr.QrError) as e:
+        qr.program_stats(bad)
+    assert what in str(e.value) or "malformed" in str(e.value), str(e.value)
+    h = ctypes.c_void_p(); buf = ctypes.create_string_buffer(bad, len(bad))
+    assert qr.lib().qr_scene_upload(buf, len(bad), 0, ctypes.byref(h)) == -1       # QR_ERR_ARG before any device is touched
+
+
+def test_compiler_accepts_every_fixture_and_reports_sizes(qr):
+    from conftest import MANIFEST
+    for name in sorted(MANIFEST):
+        info = qr.program_stats(load_blob(name))
+        assert info.n_lists > 0 and info.n_cells > 0 and info.bytes > 4096 and info.n_sched > 0, name
+        assert info.bytes % 64 == 0
+
+
+def test_compiler_survives_corrupted_snapshots(qr):
+    """Robustness of validation + list compilation + image verification: random corruption of the element, surface
+    and tile arrays either compiles into a verified image or is rejected with an error code -- never a crash,
+    never an image with an offset outside itself (qr_program_verify runs on every successful build)."""
+    import struct
+    import numpy as np
+    base = load_blob("demo02_160")
+    hdr = struct.unpack_from("<22I", base, 0)
+    n_srf, n_elm, n_tiles = hdr[4], hdr[7], hdr[8]
+    off_srf, off_elm, off_tiles = hdr[11], hdr[14], hdr[15]
+    rng = np.random.default_rng(2024)
+    L = qr.lib()
+    outcomes = {0: 0, -1: 0, -3: 0}
+    for trial in range(400):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 4))
+            val = int(rng.choice([-1, 0, 1, 2, 7, n_elm - 1, n_elm, n_srf - 1, n_srf, -2, 1 << 20, int(rng.integers(0, n_elm))]))
+            if kind == 0:       # an element field (simd, data, next, kind)
+                struct.pack_into("<i", b, off_elm + 16 * int(rng.integers(0, n_elm)) + 4 * int(rng.integers(0, 4)), val)
+            elif kind == 1:     # a tag / list-head / trnode field of a surface
+                fld = int(rng.choice([7, 11, 15, 19, 23, 34, 35, 36, 37, 38, 39, 40, 41, 44, 45, 46, 47]))
+                struct.pack_into("<i", b, off_srf + 256 * int(rng.integers(0, n_srf)) + 4 * fld, val)
+            elif kind == 2:     # a tile head
+                struct.pack_into("<i", b, off_tiles + 4 * int(rng.integers(0, n_tiles)), val)
+            else:               # a material's texture addressing
+                off_mat = hdr[12]
+                struct.pack_into("<i", b, off_mat + 128 * int(rng.integers(0, hdr[5])) + 4 * int(rng.integers(4, 10)), val)
+        info = qr.ProgramInfo()
+        buf = ctypes.create_string_buffer(bytes(b), len(b))
+        rc = L.qr_program_stats(buf, len(b), ctypes.byref(info))
+        assert rc in outcomes, (trial, rc, L.qr_last_error())
+        outcomes[rc] += 1
+    assert outcomes[0] > 0 and outcomes[-1] > 0, outcomes
+
+
 @pytest.mark.parametrize("name", ["demo01_160", "demo02_160_gf_aa4", "test13_160"])
 def test_walker_reproduces_golden_snapshot(name, tmp_path):
     """The flattener (product code, csrc/qr_walker.cpp) run inside the unmodified reference engine through the

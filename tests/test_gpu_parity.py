@@ -140,6 +140,34 @@ def test_gpu_tile_binning_keeps_frames(qr, name):
     assert c0.as_dict() == c1.as_dict()
 
 
+VARIANT_CASES = ["demo01_160", "demo02_160_gf_aa4", "demo03_160_aa2_t2500", "test13_160", "test16_160_noopt"]
+
+
+@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "2"}, {"QR_REBIN": "1"}, {"QR_REBIN": "1", "QR_BIN_TILE": "8x8"}])
+@pytest.mark.parametrize("name", VARIANT_CASES)
+def test_gpu_build_variants_match_reference(qr, name, env):
+    """The knobs that change what the upload pass builds (cull cells off / on open shapes only, tile lists from
+    the binning pass at two tile sizes) leave the reference's pixels, hit ids and ray counts untouched."""
+    import os
+    import torch
+    blob = load_blob(name)
+    base = qr.Scene(blob)
+    f0 = base.new_frame(); i0 = torch.full_like(f0, -2)
+    base.render(f0, ids=i0); _, c0 = base.render_count()
+    os.environ.update(env)
+    try:
+        scn = qr.Scene(blob)
+    finally:
+        for k in env:
+            del os.environ[k]
+    frame = scn.new_frame(); ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids); torch.cuda.synchronize()
+    assert (frame.cpu().numpy().view(np.uint32) == (load_frame(name) & 0xFFFFFF)).all()
+    assert bool((i0 == ids).all())
+    _, c1 = scn.render_count()
+    assert c0.as_dict() == c1.as_dict()
+
+
 def _hash(frame):
     """FNV-1a-64 over pixel & 0xFFFFFF, row-major (tests/golden/manifest.json 'hash'): the oracle's C helper."""
     import sys, os
@@ -168,6 +196,30 @@ def test_gpu_multi_target_launch_matches_separate_launches(qr):
         assert bool((outside == 0x55).all()), "rows outside the range must stay untouched"
     assert bool((fb[17:hb - 9] == whole_b[17:hb - 9]).all())
     assert bool((fb[:17] == 0x55).all()) and bool((fb[hb - 9:] == 0x55).all())
+
+
+def test_gpu_multi_target_launch_follows_depth_changes(qr):
+    """Nothing of a scene's launch state is cached by the multi-target path: after qr_scene_set_depth the next
+    multi-target launch renders with the new depth, exactly like a single-target launch."""
+    import torch
+    a = qr.Scene(load_blob("demo02_160_gf_d5"))
+    h = a.height
+    tg = [torch.zeros((h, a.width), dtype=torch.int32, device="cuda") for _ in range(2)]
+    m = qr.MultiRender([(a, tg[0], 0, h // 2), (a, tg[1], h // 2, h)])
+    for depth in (5, 0, 2):
+        a.set_depth(depth)
+        whole = a.render(); m(); torch.cuda.synchronize()
+        assert bool((tg[0][:h // 2] == whole[:h // 2]).all()) and bool((tg[1][h // 2:] == whole[h // 2:]).all()), f"depth {depth}"
+    d5 = a.render(); a.set_depth(0); d0 = a.render(); torch.cuda.synchronize()
+    assert not bool((d5 == d0).all()), "the fixture must depend on the recursion depth"
+
+
+def test_gpu_frame_hash_matches_manifest(qr):
+    """qr_frame_hash (product helper used by bench.py's gate) has the manifest's definition."""
+    import torch
+    scn = qr.Scene(load_blob("c1_demo01_640x480"))
+    f = scn.render(); torch.cuda.synchronize()
+    assert qr.frame_hash(f) == int(MANIFEST["c1_demo01_640x480"]["hash"], 16) == _hash(f.cpu().numpy().view(np.uint32))
 
 
 def _recamera(blob, seed):

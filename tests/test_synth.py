@@ -118,16 +118,18 @@ def test_gpu_scene_without_objects(qr, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_divergent_walk_variant_matches_oracle(qr, oracle):
-    """QR_DIV=1 selects the per-lane (divergent) list walk variant: same pixels, hit ids and ray counts as
-    the oracle (the whole GPU suite also passes with QR_DIV=1 in the environment)."""
+@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "1"}, {"QR_BIN_TILE": "8x8"}])
+def test_gpu_synth_build_variants_match_oracle(qr, oracle, env):
+    """Upload-time variants of the compiled scene: no bounding-sphere cull cells, cull on planes only, 8x8 tiles
+    from the binning pass: same pixels, hit ids and ray counts as the oracle."""
     import torch
     blob = _synth().make_scene(**MID)
-    os.environ["QR_DIV"] = "1"
+    os.environ.update(env)
     try:
         scn = qr.Scene(blob, rebin_tiles=True)
     finally:
-        del os.environ["QR_DIV"]
+        for k in env:
+            del os.environ[k]
     frame = scn.new_frame(); ids = torch.full_like(frame, -2)
     scn.render(frame, ids=ids); torch.cuda.synchronize()
     o_frame, o_ids, _ = oracle.render(blob, threads=16, want_ids=True)
