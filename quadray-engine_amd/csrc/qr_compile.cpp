@@ -266,10 +266,44 @@ struct Builder
                 open.push_back(j);
             }
         }
+        /* bounding-volume arrays get a conservative sphere of their own (ours): the union of the members' bounding
+         * spheres around the first bounded member's centre.  The walk skips an array that lies entirely behind a
+         * ray's origin or entirely beyond its current depth bound -- the reference's own test only asks whether the
+         * LINE meets the volume.  No sphere (no cull) when a member is unbounded. */
+        std::vector<BSphere> arr_sphere((size_t)n);
+        if (cull_mode >= 3)
+            for (int i = 0; i < n; i++)
+            {
+                if (!(ch[i].op & QR_OPT_BV) || !ch[i].emit) continue;
+                bool ok = true; int first = -1;
+                for (int k = i + 1; k <= ch[i].last && ok; k++)
+                    if (ch[k].emit && (ch[k].op & QR_OPT_SOLVER))
+                    {
+                        if (!(bs[ch[k].si].r < 1e18f)) ok = false;
+                        else if (first < 0) first = k;
+                    }
+                if (!ok || first < 0) continue;
+                const BSphere &c0 = bs[ch[first].si];
+                double R = 0.0;
+                for (int k = i + 1; k <= ch[i].last; k++)
+                    if (ch[k].emit && (ch[k].op & QR_OPT_SOLVER))
+                    {
+                        const BSphere &m = bs[ch[k].si];
+                        const double dx = (double)m.c[0] - c0.c[0], dy = (double)m.c[1] - c0.c[1], dz = (double)m.c[2] - c0.c[2];
+                        const double d = __builtin_sqrt(dx * dx + dy * dy + dz * dz) + (double)m.r;
+                        if (d > R) R = d;
+                    }
+                R = R * 1.0001 + 1e-4;
+                if (!(R < 1e18)) continue;
+                arr_sphere[i].c[0] = c0.c[0]; arr_sphere[i].c[1] = c0.c[1]; arr_sphere[i].c[2] = c0.c[2]; arr_sphere[i].r = (float)R * 1.0001f;
+                ch[i].op |= QR_OPF_CULL;
+            }
         /* emit */
         std::vector<int> emit_idx((size_t)n + 1, 0);
         int ne = 0;
-        for (int i = 0; i < n; i++) { emit_idx[i] = ne; if (ch[i].emit) ne++; }
+        int n_emitted = 0;
+        /* slot index of every cell: a bounding-volume cell takes two slots (its extension carries the volume) */
+        for (int i = 0; i < n; i++) { emit_idx[i] = ne; if (ch[i].emit) { ne += (ch[i].op & QR_OPT_BV) ? 2 : 1; n_emitted++; } }
         emit_idx[n] = ne;
         const uint32_t off = alloc((size_t)(ne + 1) * sizeof(CCell), 32);
         list_off[head] = off;
@@ -283,16 +317,37 @@ struct Builder
             c.r = __builtin_inff();
             if (c.op & QR_OPF_CULL)
             {
-                const BSphere &bsp = bs[ch[i].si];
+                const BSphere &bsp = (c.op & QR_OPT_BV) ? arr_sphere[i] : bs[ch[i].si];
                 c.cx = bsp.c[0]; c.cy = bsp.c[1]; c.cz = bsp.c[2]; c.r = bsp.r;
-                c.r2 = bsp.r * bsp.r; c.r2x = c.r2 * 1.01f;
+                if (!(c.op & QR_OPT_BV)) { c.r2 = bsp.r * bsp.r; c.r2x = c.r2 * 1.01f; }      /* BV: the slot holds `end` */
             }
             *at<CCell>(off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell)) = c;
+            if (c.op & QR_OPT_BV)
+            {
+                /* extension slot: what AR_ptr reads of the volume's surface record, so that the walk needs no
+                 * second, dependent load for it */
+                const qr_surface &q = v.srf[ch[i].si];
+                CBvExt x;
+                memset(&x, 0, sizeof(x));
+                for (int k = 0; k < 3; k++) x.pos[k] = q.pos[k];
+                for (int k = 0; k < 4; k++) x.sci[k] = q.sci[k];
+                *at<CBvExt>(off + (uint32_t)(emit_idx[i] + 1) * (uint32_t)sizeof(CCell)) = x;
+            }
         }
         /* END cell: already zero */
-        st.n_lists++; st.n_cells += (uint32_t)ne; st.n_dropped += (uint32_t)(n - ne);
-        /* lists reachable from this one are compiled by their owners (surface records) */
-        return off;
+        st.n_lists++; st.n_cells += (uint32_t)n_emitted; st.n_dropped += (uint32_t)(n - n_emitted);
+        /* flags in the offset's low bits: may the per-lane walk take this list, is it a long hierarchy */
+        uint32_t lf = QR_LISTF_DIV;
+        int n_bv = 0;
+        for (int i = 0; i < n; i++)
+        {
+            if (!ch[i].emit) continue;
+            if (ch[i].op & QR_OPF_CLIP) lf &= ~QR_LISTF_DIV;
+            if (ch[i].op & QR_OPT_BV) n_bv++;
+        }
+        if (n_emitted >= 96 && n_bv >= 4) lf |= QR_LISTF_LONG;
+        list_off[head] = off | lf;
+        return off | lf;
     }
 
     /* ---- clipper programs ---- */
@@ -569,25 +624,33 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     /* a list program: cells inside the list area, END-terminated, array ends inside the run */
     auto check_list = [&](uint32_t off) -> const char * {
         if (off == 0) return nullptr;
-        if (off < p.off_lists || (off & 31) || (size_t)off + 32 > limit) return "list offset out of range";
+        if (off & 28u) return "list offset carries unknown flag bits";
+        off &= ~31u;
+        if (off < p.off_lists || (size_t)off + 32 > limit) return "list offset out of range";
         if (seen_list[off / 32]) return nullptr;
         seen_list[off / 32] = 1;
         uint32_t o = off, end_cell = 0;
-        for (;; o += 32)
+        for (;;)
         {
             if ((size_t)o + 32 > limit) return "list runs off the image";
             const CCell *c = (const CCell *)(b.data() + o);
             if (c->op == 0) { end_cell = o; break; }
+            o += (c->op & QR_OPT_BV) ? 64 : 32;
         }
-        for (o = off; o < end_cell; o += 32)
+        std::vector<uint32_t> starts;           /* an array must end on a cell boundary */
+        for (o = off; o < end_cell; o += (((const CCell *)(b.data() + o))->op & QR_OPT_BV) ? 64 : 32) starts.push_back(o);
+        starts.push_back(end_cell);
+        for (size_t k = 0; k + 1 < starts.size(); k++)
         {
+            o = starts[k];
             const CCell *c = (const CCell *)(b.data() + o);
             const uint32_t t = c->op & QR_OPT_MASK;
             if (t == 0 || (t & (t - 1)) != 0) return "bad opcode";
             if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf)) return "cell surface offset out of range";
-            if (t == QR_OPT_BV && (c->end <= o || c->end > end_cell || (c->end & 31))) return "array end outside its list";
+            if (t == QR_OPT_BV && (c->end <= o + 32 || c->end > end_cell || !std::binary_search(starts.begin(), starts.end(), c->end)))
+                return "array end outside its list";
             if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
-            if ((c->op & QR_OPF_CULL) && !(t & QR_OPT_SOLVER)) return "cull flag on a cell without solver";
+            if ((c->op & QR_OPF_CULL) && !(t & (QR_OPT_SOLVER | QR_OPT_BV))) return "cull flag on a cell without solver or volume";
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
             if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";
         }

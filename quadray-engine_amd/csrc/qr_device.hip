@@ -459,8 +459,11 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
 #ifdef QR_STATS
     {
-        unsigned long long st[16];
+        unsigned long long st[24];
         HIP_TRY(hipMemcpy(st, s->d_counters + 4, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "QR_STATS per-lane walks %llu: steps %llu (%.1f per walk, %.1f lanes stepping), solve rounds %llu (%.1f lanes solving)\n",
+                st[16], st[17], st[16] ? (double)st[17] / st[16] : 0.0, st[17] ? (double)st[18] / st[17] : 0.0,
+                st[19], st[19] ? (double)st[20] / st[19] : 0.0);
         const char *nm[3] = { "shadow", "primary", "secondary" };
         for (int k = 0; k < 3; k++)
             fprintf(stderr, "QR_STATS %s: walks %llu elem-iterations %llu (%.1f per walk, %.0f%% culled) active lanes per iteration %.1f\n", nm[k],

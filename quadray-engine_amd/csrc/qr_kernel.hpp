@@ -304,7 +304,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         if (any_lane(tr))
         {
             Hit h; bool occ;
-            traverse<false>(B, tr, ray, h, occ
+            /* coherent: every ray of this round is a primary ray (neighbouring pixels) */
+            const bool coherent = !any_lane(tr && sp != 0);
+            traverse<false>(B, tr, coherent, ray, h, occ
 #ifdef QR_STATS
                             , cx.stats
 #endif
@@ -319,7 +321,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (got && sp == 0) hit_id = (hsi << 1) | h.side;
 
             Shaded o;
-            shade<COUNT>(cx, got, ray, h, o, cnt);
+            shade<COUNT>(cx, got, coherent, ray, h, o, cnt);
 
             if (got)
             {

@@ -28,11 +28,14 @@ struct CCell                    /* 32 B, 32-byte aligned */
 {
     uint32_t op;                /* QR_OPT_* type bit | flags below; 0 ends the list                       */
     uint32_t srf;               /* byte offset of the surface's DSurf                                    */
-    union { uint32_t end;       /* BV: byte offset just behind the array's last cell                     */
+    union { uint32_t end;       /* BV: byte offset just behind the array's last cell (BV cells take 64 B: CBvExt follows) */
             float r2; };        /* cull cells: R^2 of the bounding sphere                                */
     float    r2x;               /* cull cells: 1.01 R^2 (origin counts as outside the sphere beyond it)  */
     float    cx, cy, cz, r;     /* conservative world-space bounding sphere (QR_OPF_CULL cells)          */
 };
+
+/* second slot of a QR_OPT_BV cell: the fields of the volume's surface record that AR_ptr reads */
+struct CBvExt { float pos[3]; uint32_t pad; float sci[4]; };
 
 /* cell type: one bit each, so that the walk tests them with s_bitcmp in the order of their frequency
  * (a dense enum makes the compiler build a compare tree) */
@@ -59,6 +62,11 @@ struct CCell                    /* 32 B, 32-byte aligned */
 #define QR_OPF_SIDESHAD (1u << 15)  /*   ... occludes depending on the side hit (look at the props)       */
 #define QR_OPF_CLIP    (1u << 16)   /* surface has custom clippers                                        */
 #define QR_OPF_CONIC   (1u << 17)   /* conic singularity fix applies (cones, hyper-cylinders)             */
+
+/* flags in the low bits of a list offset (list programs are 32-byte aligned), carried wherever a list is referenced */
+#define QR_LISTF_DIV   1u       /* no cell has a clipper program: the per-lane walk may take this list      */
+#define QR_LISTF_LONG  2u       /* a long hierarchy (bounding-volume arrays, many cells): rays part ways on it */
+#define QR_LIST_OFF(x) ((x) & ~31u)
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
 

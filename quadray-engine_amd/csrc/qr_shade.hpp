@@ -39,7 +39,7 @@ struct Counters { u32 primary, shadow, reflect, refract; };
 struct Outer { V3 ret; int hit_id, sp, mode; };
 
 template <bool COUNT>
-__device__ __forceinline__ void shade(const Ctx &cx, bool act, const Ray &r, const Hit &h,
+__device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, const Ray &r, const Hit &h,
                                       Shaded &o, Counters &cnt)
 {
     /* per-lane (divergent) material data: vector loads at byte offsets from the blob base; everything
@@ -192,7 +192,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, const Ray &r, con
         if (QR_KNOB(2)) lm = false;
         if (QR_KNOB(1)) occ = false; else
         {
-            traverse<true>(B, lm, sr, sh, occ
+            traverse<true>(B, lm, coherent, sr, sh, occ
 #ifdef QR_STATS
                                   , cx.stats
 #endif

@@ -26,12 +26,38 @@ typedef unsigned long long lm_t;
 __device__ __forceinline__ bool lane_of(lm_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ bool any_lane(bool b) { return LM(b) != 0ull; }
 
+/*
+ * The cell code below is shared by the wave-packet walk (cell wave-uniform: masks are scalar lane masks) and by
+ * the per-lane walk (every lane its own cell: a "mask" is the lane's own predicate, because code under a
+ * per-lane opcode test only sees part of the wave).  MK<DIV> is that choice.
+ */
+template <bool DIV> struct MK;
+template <> struct MK<false>
+{
+    typedef lm_t T;
+    static __device__ __forceinline__ T of(bool c) { return LM(c); }
+    static __device__ __forceinline__ bool lane(T m) { return lane_of(m); }
+    static __device__ __forceinline__ bool any(T m) { return m != 0ull; }
+    static __device__ __forceinline__ T inv(T m) { return ~m; }
+    static __device__ __forceinline__ T none() { return 0ull; }
+};
+template <> struct MK<true>
+{
+    typedef bool T;
+    static __device__ __forceinline__ T of(bool c) { return c; }
+    static __device__ __forceinline__ bool lane(T m) { return m; }
+    static __device__ __forceinline__ bool any(T m) { return any_lane(m); }
+    static __device__ __forceinline__ T inv(T m) { return !m; }
+    static __device__ __forceinline__ T none() { return false; }
+};
+
 /* what clip() needs to know about the candidate's surface space */
+template <bool DIV>
 struct ClipIn
 {
-    V3 df, ry;              /* the diff / ray the solver read (trnode space for QR_OPF_LOCAL cells)        */
-    lm_t dmask;             /* quadric: near-zero discriminant lanes (conic fix)                           */
-    u32 amask;              /* quadric: sign of `a`                                                        */
+    V3 df, ry;                  /* the diff / ray the solver read (trnode space for QR_OPF_LOCAL cells)    */
+    typename MK<DIV>::T dmask;  /* quadric: near-zero discriminant lanes (conic fix)                       */
+    u32 amask;                  /* quadric: sign of `a`                                                    */
 };
 
 /* the first 80 bytes of a DSurf in SGPRs */
@@ -114,13 +140,15 @@ __device__ __forceinline__ lm_t clip_box(lm_t m, float tbuf, float tmin, float t
 /* CC_clp, tracer.cpp:1597-2160.  Returns the lanes of `m` whose hit at `t`  */
 /* survives; `loc` is the local hit (ctx_NEW_* of the surface's space).      */
 /* ------------------------------------------------------------------------ */
-__device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
-                                     const ClipIn &ci, float t, int side, lm_t m, V3 &loc)
+template <bool DIV>
+__device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
+                                                    const ClipIn<DIV> &ci, float t, int side, typename MK<DIV>::T m, V3 &loc)
 {
+    typedef MK<DIV> K;
     /* the opcode is re-read through an opaque copy: otherwise everything that only depends on it (the whole
      * axis decode of the conic fix, every flag as a 64-bit mask) is hoisted in front of the candidate loop and
      * paid by every cell */
-    asm volatile("" : "+s"(op));
+    if constexpr (!DIV) asm volatile("" : "+s"(op));
     float x4, x5, x6;
     V3 hit;
 
@@ -147,17 +175,17 @@ __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray 
     if (op & QR_OPF_CONIC)
     {
         u32 fl = s.flags;
-        asm volatile("" : "+s"(fl));
+        if constexpr (!DIV) asm volatile("" : "+s"(fl));
         const u32 conic = DF_CONIC(fl);
         const u32 mi = DF_MAP(fl, 0), mj = DF_MAP(fl, 1), mk = DF_MAP(fl, 2);
         float x0, x1, x2, x3;
         x1 = vget(nw, (int)mi); x1 = x1 * x1; x0 = x1;
         if (conic != 2) { x2 = vget(nw, (int)mj); x2 = x2 * x2; x0 = x0 + x2; }
         x3 = vget(nw, (int)mk); x3 = x3 * x3; x0 = x0 + x3;
-        const lm_t hm = LM(clt(x0, s.t_eps)) & ci.dmask;
-        if (hm != 0)
+        const typename K::T hm = K::of(clt(x0, s.t_eps)) & ci.dmask;
+        if (K::any(hm))
         {
-            if (lane_of(hm))
+            if (K::lane(hm))
             {
                 const u32 sm = QR_SMASK;
                 const float one = 1.0f;
@@ -199,10 +227,17 @@ __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray 
 
     /* depth + near test (1600-1640) and axis min/max (1874-1927): unclipped axes hold -inf / +inf, so the six
      * compares are unconditional (a lane still in `m` has a finite hit point) */
-    m = clip_box(m, tbuf, r.tmin, t, x4, x5, x6, s);
+    if constexpr (DIV)
+    {
+        m = m && cgt(tbuf, t) && clt(r.tmin, t)
+              && cle(s.min0, x4) && cge(s.max0, x4) && cle(s.min1, x5) && cge(s.max1, x5)
+              && cle(s.min2, x6) && cge(s.max2, x6);
+    }
+    else m = clip_box(m, tbuf, r.tmin, t, x4, x5, x6, s);
 
-    /* custom clipping, 1931-2151: the surface's clipper program */
-    if ((op & QR_OPF_CLIP) && m != 0)
+    /* custom clipping, 1931-2151: the surface's clipper program (wave-uniform cells only: the per-lane walk
+     * hands cells with clippers to the uniform path one at a time) */
+    if constexpr (!DIV) if ((op & QR_OPF_CLIP) && m != 0)
     {
         lm_t c_acc = 0;
         V3 cxyz = {0.0f, 0.0f, 0.0f};                   /* the hit in the cached clipper trnode's space */
@@ -276,6 +311,259 @@ __device__ __forceinline__ lm_t clip(BaseP B, const SurfS &s, u32 op, const Ray 
     return m;
 }
 
+/* AR_ptr 3955-4054: does the line hit the array's bounding volume? */
+__device__ __forceinline__ bool bv_hit(const V3 &ry, const V3 &df, float sci0, float sci1, float sci2, float sci3)
+{
+    float x0, x1, x2, x3, x4, x5, x6, x7;
+    x1 = ry.x; x0 = sci0 * x1; x5 = df.x; x7 = sci0 * x5;
+    x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
+    x2 = ry.y; x0 = sci1 * x2; x6 = df.y; x7 = sci1 * x6;
+    x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+    x2 = ry.z; x0 = sci2 * x2; x6 = df.z; x7 = sci2 * x6;
+    x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
+    x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+    x5 = x5 - sci3;
+    x5 = x5 * x1;
+    x3 = x3 * x3;
+    x3 = x3 - x5;
+    return cle(0.0f, x3);
+}
+
+/* per-lane state of one list walk */
+struct WalkState
+{
+    V3 txyz, trijk;         /* trnode cache: diff and ray in the trnode's space                             */
+    float tbuf, tbd;        /* ctx_T_BUF and tbuf * |dir|^2 (cull)                                          */
+    u32 resume;             /* packet walk: the lane takes part in cells at offsets >= resume;
+                             * 0xFFFFFFFF: shadow ray occluded, the ray has left the walk                   */
+};
+
+/*
+ * One cell with a solver for the lanes that are active: diff / ray in the surface's space, the solver,
+ * candidate roots through clip(), depth write (or occlusion for shadow rays).
+ * DIV = false: `op`, `srf_off` and the record `s` are wave-uniform (SGPRs);
+ * DIV = true : every lane brings its own cell and record (the per-lane walk); cells with clipper programs are
+ *              not allowed here.
+ */
+/* diff / ray in a cell's space, tracer.cpp:1352-1556: world, cached trnode space, or the surface's own transform */
+__device__ __forceinline__ void cell_space(BaseP B, u32 op, u32 srf_off, float pos0, float pos1, float pos2,
+                                           const Ray &r, const WalkState &w, V3 &df, V3 &ry)
+{
+    if (op & QR_OPF_CACHED)
+    {
+        df.x = w.txyz.x - pos0; df.y = w.txyz.y - pos1; df.z = w.txyz.z - pos2;
+        ry = w.trijk;
+    }
+    else
+    {
+        df.x = r.org.x - pos0; df.y = r.org.y - pos1; df.z = r.org.z - pos2;
+        ry = r.dir;
+        if (op & QR_OPF_OWN)
+        {
+            df = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, df);
+            ry = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
+        }
+    }
+}
+
+template <bool SHADOW, bool DIV>
+__device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const SurfS &s, const Ray &r,
+                                           float dd, WalkState &w, Hit &h)
+{
+    typedef MK<DIV> K;
+    typedef typename K::T mask_t;
+    /* ---- diff / ray in the surface's space, 1352-1556 ---- */
+    ClipIn<DIV> ci;
+    ci.dmask = K::none(); ci.amask = 0;
+    cell_space(B, op, srf_off, s.pos0, s.pos1, s.pos2, r, w, ci.df, ci.ry);
+    /* a secondary ray on its own surface starts from the parent's local hit, 1352-1373 */
+    const mask_t same = K::of(srf_off == r.osrf);
+    if (K::any(same))
+    {
+        const bool sl = K::lane(same);
+        ci.df.x = sl ? r.ploc.x : ci.df.x; ci.df.y = sl ? r.ploc.y : ci.df.y; ci.df.z = sl ? r.ploc.z : ci.df.z;
+    }
+    const V3 ry = ci.ry, df = ci.df;
+
+    {
+        /* up to two candidate roots per lane, in the lane's own order */
+        float ct0 = 0.0f, ct1 = 0.0f;
+        int   cs0 = 0, cs1 = 0;
+        mask_t cm0 = K::none(), cm1 = K::none();
+        int   ncand = 0;
+
+        if (op & QR_OPT_PLANE)
+        {
+            /* PL_ptr 4062-4136 */
+            const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
+            const u32 sg = (op & QR_OPF_SGNK) ? QR_SMASK : 0u;
+            const float dk = fxor(axis3(df, kx, ky), sg ^ QR_SMASK);
+            const float rk = fxor(axis3(ry, kx, ky), sg);
+            /* Pre-test (ours): the hit only survives clip() if t_min < t < t_buf.  With t_min >= 0 a
+             * quotient of opposite signs cannot, and |dk| >= |rk| * t_buf * (1 + 2^-20) means
+             * t >= t_buf whatever the rounding of the division; dropping those lanes here changes
+             * nothing, and when no lane is left the wave skips the IEEE division and clip(). */
+            const mask_t opposite = K::of(((f2u(dk) ^ f2u(rk)) & QR_SMASK) != 0);
+            const mask_t beyond = K::of(fabs_bits(dk) >= fabs_bits(rk) * (w.tbuf * 1.000001f));
+            cm0 = K::of(cne(0.0f, rk)) & K::inv(same) & K::inv((opposite | beyond) & K::of(r.tmin >= 0.0f));
+            if (K::any(cm0)) { ct0 = dk / rk; ncand = 1; }
+            cs0 = clt(rk, 0.0f) ? 0 : 1;
+        }
+        else
+        {
+            float a, b, cq, d;
+            if (op & QR_OPT_QUADRIC)
+            {
+                /* QD_ptr 4378-4447 */
+                float x0, x1, x2, x3, x4, x5, x6, x7;
+                x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
+                x7 = x7 - s.scj0; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.scj0; x5 = x5 * x7;
+                x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
+                x7 = x7 - s.scj1; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj1; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
+                x7 = x7 - s.scj2; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj2; x6 = x6 * x7;
+                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
+                x5 = x5 - s.sci3;
+                x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
+                a = x1; b = x4; cq = x6; d = x3;
+            }
+            else
+            {
+                /* TP_ptr 4216-4277 */
+                const bool ix = (op & QR_OPF_IX) != 0, iy = (op & QR_OPF_IY) != 0;
+                const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
+                const V3 sc3 = {s.sci0, s.sci1, s.sci2};
+                float x0, x1, x2, x3, x4, x5, x6, x7;
+                x1 = axis3(ry, ix, iy); x5 = axis3(df, ix, iy); x3 = axis3(sc3, ix, iy);
+                x2 = axis3(ry, kx, ky); x6 = axis3(df, kx, ky); x4 = axis3(sc3, kx, ky);
+                x0 = x5; x7 = x6;
+                x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
+                x5 = fabs_bits(x5);
+                x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
+                x4 = axis3(sc3, kx, ky);
+                x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
+                x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
+                a = x1; b = x3; cq = x0; d = x5;
+            }
+
+            /* QD_rts 4449-4658 */
+            const u32 sm = QR_SMASK;
+            const mask_t xmask = K::of(cle(0.0f, d));
+            /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
+            if (K::any(xmask))
+            {
+                b = fxor(b, sm);
+                const mask_t dmask = xmask & K::of(clt(d, s.d_eps));
+                ci.dmask = dmask;
+
+                const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
+                const float bd = b + sd;
+                const bool m_pos = cle(0.0f, sd);
+                /* m_neg = cgt(0, sd) = !m_pos unless sd is NaN (then both selections come out 0) */
+                const bool m_neg = cgt(0.0f, sd);
+                const float t2n = u2f((m_neg ? f2u(cq) : 0u) | (m_pos ? f2u(bd) : 0u));
+                const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(cq) : 0u));
+                float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
+                float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
+                a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
+
+                const u32 amask = sm & f2u(a);
+                ci.amask = amask;
+                if (K::any(dmask))
+                {
+                    if (K::lane(dmask))
+                    {
+                        if (ceq(t1n, 0.0f)) t1d = 1.0f;
+                        if (ceq(t2n, 0.0f)) t2d = 1.0f;
+                    }
+                }
+                float t1 = t1n / t1d;
+                float t2 = t2n / t2d;
+                const mask_t t1msk = K::of(cne(t1d, 0.0f));
+                const mask_t t2msk = K::of(cne(t2d, 0.0f));
+                if (K::any(dmask))
+                {
+                    if (K::lane(dmask))
+                    {
+                        float tdf = t1 - t2;
+                        tdf = fxor(tdf, amask);
+                        const bool f = cle(0.0f, tdf);
+                        tdf = f ? tdf : 0.0f;
+                        float eps = f ? s.t_eps : 0.0f;
+                        eps = eps * t1;
+                        eps = fabs_bits(eps);
+                        tdf = tdf * -0.5f;
+                        tdf = tdf - eps;
+                        tdf = fxor(tdf, amask);
+                        tdf = K::lane(t1msk & t2msk) ? tdf : 0.0f;
+                        t1 = t1 + tdf;
+                        t2 = t2 - tdf;
+                    }
+                }
+
+                const bool inner_first = cgt(0.0f, a);      /* only read where xmask holds */
+                mask_t mo = xmask & t1msk, mi2 = xmask & t2msk;
+                if (K::any(same))
+                {
+                    /* CHECK_SIDE 531-540: on its own surface a ray that left through the outer side
+                     * (flags 0: reflected off it, 3: passed through from inside) skips the inner root,
+                     * one that left through the inner side (1, 2) the outer root */
+                    const mask_t so = K::of(((r.oflg ^ (r.oflg >> 1)) & 1) != 0);
+                    mo = mo & K::inv(same & so);
+                    mi2 = mi2 & K::inv(same & K::inv(so));
+                }
+                ncand = 2;
+                ct0 = inner_first ? t2 : t1; ct1 = inner_first ? t1 : t2;
+                cs0 = inner_first ? 1 : 0;   cs1 = inner_first ? 0 : 1;
+                const mask_t inf = K::of(inner_first);
+                cm0 = (inf & mi2) | (K::inv(inf) & mo); cm1 = (inf & mo) | (K::inv(inf) & mi2);
+            }
+        }
+
+        mask_t done = K::none();
+        /* per-lane cells: every lane brings its own number of candidates, so both slots are visited (a slot that
+         * was not filled has an empty mask) */
+        const int np = DIV ? 2 : ncand;
+#pragma nounroll
+        for (int p = 0; p < np; p++)
+        {
+            const float t = p == 0 ? ct0 : ct1;
+            const int side = p == 0 ? cs0 : cs1;
+            mask_t m = (p == 0 ? cm0 : cm1) & K::inv(done);
+            if (!K::any(m)) continue;
+            V3 loc;
+            m = clip<DIV>(B, s, op, r, w.tbuf, ci, t, side, m, loc);
+            done = done | m;
+            if (K::lane(m))
+            {
+                if (SHADOW)
+                {
+                    /* CHECK_SHAD 549-589: by the surface's material (static class in the opcode) */
+                    u32 opl = op;
+                    if constexpr (!DIV) asm volatile("" : "+s"(opl));
+                    bool casts = (opl & QR_OPF_NOSHAD) == 0;
+                    if (opl & QR_OPF_SIDESHAD)
+                    {
+                        const QR_CONST DSurf *P = (const QR_CONST DSurf *)(B + srf_off);
+                        const int props = side ? P->props1 : P->props0;
+                        casts = !((props & QR_PROP_LIGHT) || ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT)));
+                    }
+                    if (casts) w.resume = 0xFFFFFFFFu;        /* occluded: the ray leaves the walk */
+                }
+                else
+                {
+                    /* PAINT_FRAG 653-662: depth write; shading is deferred */
+                    w.tbuf = t; w.tbd = t * dd;
+                    h.t = t; h.srf = srf_off; h.side = side;
+                    h.loc = loc;
+                }
+            }
+        }
+    }
+        }
+
 /*
  * OO_cyc for the lanes of a wave that share the list program at `head` (wave-uniform, not 0).
  * SHADOW: any-hit walk, ends as soon as every ray is occluded.
@@ -287,15 +575,16 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
                                           )
 {
-    V3 txyz = {0, 0, 0}, trijk = {0, 0, 0};     /* trnode cache: diff and ray in the trnode's space */
-    float tbuf = r.tmax;
-    u32 resume = 0;                             /* the lane takes part in cells at offsets >= resume */
+    WalkState w;
+    w.txyz = {0, 0, 0}; w.trijk = {0, 0, 0};
+    w.tbuf = r.tmax;
+    w.resume = 0;
     const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
     /* only the cull uses the ray length: an upper bound is enough there, so the 1-instruction
      * approximate square root (1 ulp) inflated by 2^-20 replaces the IEEE expansion */
     const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
     const float dde = dd * 1e-5f;
-    float tbd = tbuf * dd;
+    w.tbd = w.tbuf * dd;
     u32 pos = __builtin_amdgcn_readfirstlane(head);
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0, st_skip = 0;
@@ -307,13 +596,25 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
         const u32 op = c.s0;
         if (op == 0) break;
         const u32 srf_off = c.s1;
-        const lm_t on = LM(resume <= pos);
-        u32 next = pos + 32;
+        const lm_t on = LM(w.resume <= pos);
+        u32 next = pos + ((op & QR_OPT_BV) ? 64u : 32u);        /* a bounding-volume cell carries an extension slot */
         bool full = true;
 #ifdef QR_STATS
         st_iter++; st_lanes += __popcll(on);
 #endif
-        if (op & QR_OPF_CULL)
+        lm_t far = 0;                           /* bounding volume: lanes for which the whole array is out of reach */
+        if ((op & (QR_OPF_CULL | QR_OPT_BV)) == (QR_OPF_CULL | QR_OPT_BV))
+        {
+            /* the array's own conservative sphere (qr_compile.cpp): entirely behind the origin, or entirely beyond
+             * the current depth bound -> nothing inside can be hit by this ray: treated as a miss of the volume */
+            const float R = u2f(c.s7);
+            const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
+            const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+            far = on & (LM(__builtin_fmaf(R, dlen, b) < 0.0f) | LM(__builtin_fmaf(-R, dlen, b) > w.tbd));
+            if (far != 0) { if (lane_of(far)) w.resume = c.s2; }
+            full = (on & ~far) != 0;
+        }
+        else if (op & QR_OPF_CULL)
         {
             /*
              * Wave-level cull (ours, not in the reference): the cell carries a conservative world-space
@@ -331,7 +632,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
             const float q = oc2 - R2;
             const lm_t miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
-                            | LM(__builtin_fmaf(-R, dlen, b) > tbd);
+                            | LM(__builtin_fmaf(-R, dlen, b) > w.tbd);
             const lm_t need = on & ~(miss & LM(srf_off != r.osrf));
             full = need != 0;
 #ifdef QR_STATS
@@ -349,254 +650,40 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
                     const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
                     V3 d;
                     d.x = r.org.x - u2f(p0.x); d.y = r.org.y - u2f(p0.y); d.z = r.org.z - u2f(p0.z);
-                    txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
-                    trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
+                    w.txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
+                    w.trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
                 }
+            }
+            else if (op & QR_OPT_BV)
+            {
+                /* AR_ptr 3955-4054; the volume travels with the cell (CBvExt) */
+                const u32x8 x = *(const QR_CONST u32x8 *)(B + pos + 32);
+                if (lane_of(on & ~far))
+                {
+                    V3 df, ry;
+                    cell_space(B, op, srf_off, u2f(x.s0), u2f(x.s1), u2f(x.s2), r, w, df, ry);
+                    if (!bv_hit(ry, df, u2f(x.s4), u2f(x.s5), u2f(x.s6), u2f(x.s7))) w.resume = c.s2;   /* back at the array's end */
+                }
+                /* the reference jumps a whole packet behind an array whose bounding volume no lane hits
+                 * (tracer.cpp:4040-4054); rays that were off already wait for the end of an enclosing array,
+                 * which lies at or behind this array's end (arrays nest, qr_compile.cpp) */
+                if (LM(w.resume <= pos) == 0) next = c.s2;
             }
             else
             {
                 SurfS s;
                 ld_surf(B, srf_off, s);
-
-                if (lane_of(on))
+                if (lane_of(on)) solve_cell<SHADOW, false>(B, op, srf_off, s, r, dd, w, h);
+                if (SHADOW)
                 {
-                    /* ---- diff / ray in the surface's space, 1352-1556 ---- */
-                    ClipIn ci;
-                    ci.dmask = 0; ci.amask = 0;
-                    if (op & QR_OPF_CACHED)
-                    {
-                        ci.df.x = txyz.x - s.pos0; ci.df.y = txyz.y - s.pos1; ci.df.z = txyz.z - s.pos2;
-                        ci.ry = trijk;
-                    }
-                    else
-                    {
-                        ci.df.x = r.org.x - s.pos0; ci.df.y = r.org.y - s.pos1; ci.df.z = r.org.z - s.pos2;
-                        ci.ry = r.dir;
-                        if (op & QR_OPF_OWN)
-                        {
-                            ci.df = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, ci.df);
-                            ci.ry = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
-                        }
-                    }
-                    /* a secondary ray on its own surface starts from the parent's local hit, 1352-1373 */
-                    const lm_t same = LM(srf_off == r.osrf);
-                    if (same != 0)
-                    {
-                        const bool sl = lane_of(same);
-                        ci.df.x = sl ? r.ploc.x : ci.df.x; ci.df.y = sl ? r.ploc.y : ci.df.y; ci.df.z = sl ? r.ploc.z : ci.df.z;
-                    }
-                    const V3 ry = ci.ry, df = ci.df;
-
-                    if (op & QR_OPT_BV)
-                    {
-                        /* AR_ptr 3955-4054 */
-                        float x0, x1, x2, x3, x4, x5, x6, x7;
-                        x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
-                        x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x5 = x5 * x7;
-                        x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
-                        x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                        x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
-                        x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x6 = x6 * x7;
-                        x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                        x5 = x5 - s.sci3;
-                        x5 = x5 * x1;
-                        x3 = x3 * x3;
-                        x3 = x3 - x5;
-                        if (!cle(0.0f, x3)) resume = c.s2;      /* misses the volume: back at the array's end */
-                    }
-                    else
-                    {
-                        /* up to two candidate roots per lane, in the lane's own order */
-                        float ct0 = 0.0f, ct1 = 0.0f;
-                        int   cs0 = 0, cs1 = 0;
-                        lm_t  cm0 = 0, cm1 = 0;
-                        int   ncand = 0;
-
-                        if (op & QR_OPT_PLANE)
-                        {
-                            /* PL_ptr 4062-4136 */
-                            const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
-                            const u32 sg = (op & QR_OPF_SGNK) ? QR_SMASK : 0u;
-                            const float dk = fxor(axis3(df, kx, ky), sg ^ QR_SMASK);
-                            const float rk = fxor(axis3(ry, kx, ky), sg);
-                            /* Pre-test (ours): the hit only survives clip() if t_min < t < t_buf.  With t_min >= 0 a
-                             * quotient of opposite signs cannot, and |dk| >= |rk| * t_buf * (1 + 2^-20) means
-                             * t >= t_buf whatever the rounding of the division; dropping those lanes here changes
-                             * nothing, and when no lane is left the wave skips the IEEE division and clip(). */
-                            const lm_t opposite = LM(((f2u(dk) ^ f2u(rk)) & QR_SMASK) != 0);
-                            const lm_t beyond = LM(fabs_bits(dk) >= fabs_bits(rk) * (tbuf * 1.000001f));
-                            cm0 = LM(cne(0.0f, rk)) & ~same & ~((opposite | beyond) & LM(r.tmin >= 0.0f));
-                            if (cm0 != 0) { ct0 = dk / rk; ncand = 1; }
-                            cs0 = clt(rk, 0.0f) ? 0 : 1;
-                        }
-                        else
-                        {
-                            float a, b, cq, d;
-                            if (op & QR_OPT_QUADRIC)
-                            {
-                                /* QD_ptr 4378-4447 */
-                                float x0, x1, x2, x3, x4, x5, x6, x7;
-                                x1 = ry.x; x0 = s.sci0 * x1; x5 = df.x; x7 = s.sci0 * x5;
-                                x7 = x7 - s.scj0; x3 = x1; x1 = x1 * x0; x3 = x3 * x7; x7 = x7 - s.scj0; x5 = x5 * x7;
-                                x2 = ry.y; x0 = s.sci1 * x2; x6 = df.y; x7 = s.sci1 * x6;
-                                x7 = x7 - s.scj1; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj1; x6 = x6 * x7;
-                                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                                x2 = ry.z; x0 = s.sci2 * x2; x6 = df.z; x7 = s.sci2 * x6;
-                                x7 = x7 - s.scj2; x4 = x2; x2 = x2 * x0; x4 = x4 * x7; x7 = x7 - s.scj2; x6 = x6 * x7;
-                                x1 = x1 + x2; x3 = x3 + x4; x5 = x5 + x6;
-                                x5 = x5 - s.sci3;
-                                x6 = x5; x5 = x5 * x1; x4 = x3; x3 = x3 * x3; x3 = x3 - x5;
-                                a = x1; b = x4; cq = x6; d = x3;
-                            }
-                            else
-                            {
-                                /* TP_ptr 4216-4277 */
-                                const bool ix = (op & QR_OPF_IX) != 0, iy = (op & QR_OPF_IY) != 0;
-                                const bool kx = (op & QR_OPF_KX) != 0, ky = (op & QR_OPF_KY) != 0;
-                                const V3 sc3 = {s.sci0, s.sci1, s.sci2};
-                                float x0, x1, x2, x3, x4, x5, x6, x7;
-                                x1 = axis3(ry, ix, iy); x5 = axis3(df, ix, iy); x3 = axis3(sc3, ix, iy);
-                                x2 = axis3(ry, kx, ky); x6 = axis3(df, kx, ky); x4 = axis3(sc3, kx, ky);
-                                x0 = x5; x7 = x6;
-                                x6 = x6 * x1; x5 = x5 * x2; x5 = x5 - x6; x5 = x5 * x5; x5 = x5 * x3; x5 = x5 * x4;
-                                x5 = fabs_bits(x5);
-                                x6 = x3; x3 = x3 * x0; x4 = x4 * x7; x3 = x3 * x1; x4 = x4 * x2; x3 = x3 + x4;
-                                x4 = axis3(sc3, kx, ky);
-                                x0 = x0 * x0; x7 = x7 * x7; x0 = x0 * x6; x7 = x7 * x4; x0 = x0 + x7;
-                                x1 = x1 * x1; x2 = x2 * x2; x1 = x1 * x6; x2 = x2 * x4; x1 = x1 + x2;
-                                a = x1; b = x3; cq = x0; d = x5;
-                            }
-
-                            /* QD_rts 4449-4658 */
-                            const u32 sm = QR_SMASK;
-                            const lm_t xmask = LM(cle(0.0f, d));
-                            /* CHECK_MASK(OO_end, NONE, xmask), 4455 */
-                            if (xmask != 0)
-                            {
-                                b = fxor(b, sm);
-                                const lm_t dmask = xmask & LM(clt(d, s.d_eps));
-                                ci.dmask = dmask;
-
-                                const float sd = fxor(__builtin_sqrtf(d), sm & f2u(b));
-                                const float bd = b + sd;
-                                const bool m_pos = cle(0.0f, sd);
-                                /* m_neg = cgt(0, sd) = !m_pos unless sd is NaN (then both selections come out 0) */
-                                const bool m_neg = cgt(0.0f, sd);
-                                const float t2n = u2f((m_neg ? f2u(cq) : 0u) | (m_pos ? f2u(bd) : 0u));
-                                const float t1n = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(cq) : 0u));
-                                float t2d = u2f((m_neg ? f2u(bd) : 0u) | (m_pos ? f2u(a) : 0u));
-                                float t1d = u2f((m_neg ? f2u(a) : 0u)  | (m_pos ? f2u(bd) : 0u));
-                                a = u2f((m_pos ? f2u(a) : 0u) | (m_neg ? f2u(a) : 0u));
-
-                                const u32 amask = sm & f2u(a);
-                                ci.amask = amask;
-                                if (dmask != 0)
-                                {
-                                    if (lane_of(dmask))
-                                    {
-                                        if (ceq(t1n, 0.0f)) t1d = 1.0f;
-                                        if (ceq(t2n, 0.0f)) t2d = 1.0f;
-                                    }
-                                }
-                                float t1 = t1n / t1d;
-                                float t2 = t2n / t2d;
-                                const lm_t t1msk = LM(cne(t1d, 0.0f));
-                                const lm_t t2msk = LM(cne(t2d, 0.0f));
-                                if (dmask != 0)
-                                {
-                                    if (lane_of(dmask))
-                                    {
-                                        float tdf = t1 - t2;
-                                        tdf = fxor(tdf, amask);
-                                        const bool f = cle(0.0f, tdf);
-                                        tdf = f ? tdf : 0.0f;
-                                        float eps = f ? s.t_eps : 0.0f;
-                                        eps = eps * t1;
-                                        eps = fabs_bits(eps);
-                                        tdf = tdf * -0.5f;
-                                        tdf = tdf - eps;
-                                        tdf = fxor(tdf, amask);
-                                        tdf = lane_of(t1msk & t2msk) ? tdf : 0.0f;
-                                        t1 = t1 + tdf;
-                                        t2 = t2 - tdf;
-                                    }
-                                }
-
-                                const bool inner_first = cgt(0.0f, a);      /* only read where xmask holds */
-                                lm_t mo = xmask & t1msk, mi2 = xmask & t2msk;
-                                if (same != 0)
-                                {
-                                    /* CHECK_SIDE 531-540: on its own surface a ray that left through the outer side
-                                     * (flags 0: reflected off it, 3: passed through from inside) skips the inner root,
-                                     * one that left through the inner side (1, 2) the outer root */
-                                    const lm_t so = LM(((r.oflg ^ (r.oflg >> 1)) & 1) != 0);
-                                    mo &= ~(same & so);
-                                    mi2 &= ~(same & ~so);
-                                }
-                                ncand = 2;
-                                ct0 = inner_first ? t2 : t1; ct1 = inner_first ? t1 : t2;
-                                cs0 = inner_first ? 1 : 0;   cs1 = inner_first ? 0 : 1;
-                                const lm_t inf = LM(inner_first);
-                                cm0 = (inf & mi2) | (~inf & mo); cm1 = (inf & mo) | (~inf & mi2);
-                            }
-                        }
-
-                        lm_t done = 0;
-#pragma nounroll
-                        for (int p = 0; p < ncand; p++)
-                        {
-                            const float t = p == 0 ? ct0 : ct1;
-                            const int side = p == 0 ? cs0 : cs1;
-                            lm_t m = (p == 0 ? cm0 : cm1) & ~done;
-                            if (m == 0) continue;
-                            V3 loc;
-                            m = clip(B, s, op, r, tbuf, ci, t, side, m, loc);
-                            done |= m;
-                            if (lane_of(m))
-                            {
-                                if (SHADOW)
-                                {
-                                    /* CHECK_SHAD 549-589: by the surface's material (static class in the opcode) */
-                                    u32 opl = op;
-                                    asm volatile("" : "+s"(opl));
-                                    bool casts = (opl & QR_OPF_NOSHAD) == 0;
-                                    if (opl & QR_OPF_SIDESHAD)
-                                    {
-                                        const QR_CONST DSurf *P = (const QR_CONST DSurf *)(B + srf_off);
-                                        const int props = side ? P->props1 : P->props0;
-                                        casts = !((props & QR_PROP_LIGHT) || ((props & QR_PROP_TRANSP) && !(props & QR_PROP_REFRACT)));
-                                    }
-                                    if (casts) resume = 0xFFFFFFFFu;        /* occluded: the ray leaves the walk */
-                                }
-                                else
-                                {
-                                    /* PAINT_FRAG 653-662: depth write; shading is deferred */
-                                    tbuf = t; tbd = t * dd;
-                                    h.t = t; h.srf = srf_off; h.side = side;
-                                    h.loc = loc;
-                                }
-                            }
-                        }
-                    }
-                }
-
-                if (op & QR_OPT_BV)
-                {
-                    /* the reference jumps a whole packet behind an array whose bounding volume no lane hits
-                     * (tracer.cpp:4040-4054); rays that were off already wait for the end of an enclosing array,
-                     * which lies at or behind this array's end (arrays nest, qr_compile.cpp) */
-                    if (LM(resume <= pos) == 0) next = c.s2;
-                }
-                else if (SHADOW)
-                {
-                    if (LM(resume != 0xFFFFFFFFu) == 0) break;      /* every ray of the group is occluded */
+                    if (LM(w.resume != 0xFFFFFFFFu) == 0) break;      /* every ray of the group is occluded */
                 }
             }
         }
+        if (!full && far != 0) { if (LM(w.resume <= pos) == 0) next = c.s2; }      /* nobody enters the array */
         pos = next;
     }
-    if (SHADOW) occluded = resume == 0xFFFFFFFFu;
+    if (SHADOW) occluded = w.resume == 0xFFFFFFFFu;
 #ifdef QR_STATS
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
     {
@@ -609,11 +696,166 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
 }
 
+/* SurfS of a per-lane cell: five 16-byte vector loads */
+__device__ __forceinline__ void ld_surf_lane(BaseP B, u32 off, SurfS &s)
+{
+    const u32x4 a = *(const QR_CONST u32x4 *)(B + off), b = *(const QR_CONST u32x4 *)(B + off + 16),
+                c = *(const QR_CONST u32x4 *)(B + off + 32), d = *(const QR_CONST u32x4 *)(B + off + 48),
+                e = *(const QR_CONST u32x4 *)(B + off + 64);
+    s.pos0 = u2f(a.x); s.pos1 = u2f(a.y); s.pos2 = u2f(a.z); s.clip = a.w;
+    s.min0 = u2f(b.x); s.min1 = u2f(b.y); s.min2 = u2f(b.z); s.d_eps = u2f(b.w);
+    s.max0 = u2f(c.x); s.max1 = u2f(c.y); s.max2 = u2f(c.z); s.t_eps = u2f(c.w);
+    s.sci0 = u2f(d.x); s.sci1 = u2f(d.y); s.sci2 = u2f(d.z); s.sci3 = u2f(d.w);
+    s.scj0 = u2f(e.x); s.scj1 = u2f(e.y); s.scj2 = u2f(e.z); s.flags = e.w;
+}
+
+/* per-lane form of the cell cull of walk_list: c0 = {op, srf, R^2, 1.01 R^2}, c1 = {cx, cy, cz, R} */
+__device__ __forceinline__ bool div_culled(const u32x4 &c0, const u32x4 &c1, const Ray &r, float dd, float dde, float dlen, float tbd)
+{
+    const float R = u2f(c1.w), R2 = u2f(c0.z), R2x = u2f(c0.w);
+    const float ocx = u2f(c1.x) - r.org.x, ocy = u2f(c1.y) - r.org.y, ocz = u2f(c1.z) - r.org.z;
+    const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+    const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+    const float q = oc2 - R2;
+    const bool miss = ((oc2 > R2x) & (__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
+                    | (__builtin_fmaf(-R, dlen, b) > tbd);
+    return miss & (c0.y != r.osrf);
+}
+
+#ifndef QR_DIV_BATCH
+#define QR_DIV_BATCH 24     /* per-lane walk: solve as soon as this many lanes hold a candidate cell */
+#endif
+
 /*
- * Wave-wide traversal: lanes with `active` walk their lists; lanes that share a list head are walked together.
+ * PER-LANE walk for incoherent rays: every lane walks ITS OWN list at its own pace (cells and records through
+ * vector loads).  A wave-packet walk visits the union of what its rays need -- for the secondary rays of a scene
+ * with thousands of small objects that is 1300 cells with 5 of 64 lanes interested in each -- while here a ray
+ * that misses a bounding volume jumps behind the array alone and a ray whose bounding-sphere test fails steps on
+ * alone.  The walk alternates two phases so that both run with most lanes busy: STEP (lanes without a candidate
+ * advance one cell: END, trnode transform, bounding volume, cull test) and SOLVE (lanes that stand on a cell
+ * they may hit run solver + clip, all together, once QR_DIV_BATCH of them wait or nobody can step any more).
+ * Per ray the cells are met in list order, so depth-test ties resolve as in the packet walk; results are the same
+ * (a packet of width one).  Only for lists without clipper programs (QR_LISTF_DIV, set by the compiler).
  */
 template <bool SHADOW>
-__device__ __forceinline__ void traverse(BaseP B, bool active, const Ray &r, Hit &h, bool &occluded
+__device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit &h, bool &occluded
+#ifdef QR_STATS
+                                         , unsigned long long *stats
+#endif
+                                         )
+{
+    WalkState w;
+    w.txyz = {0, 0, 0}; w.trijk = {0, 0, 0};
+    w.tbuf = r.tmax;
+    w.resume = 0;
+    const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
+    const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    const float dde = dd * 1e-5f;
+    w.tbd = w.tbuf * dd;
+    u32 pos = active ? (r.list & ~31u) : 0u;    /* 0: the lane has finished */
+    u32 p_op = 0, p_srf = 0;                    /* the candidate cell the lane stands on (p_op == 0: none) */
+#ifdef QR_STATS
+    unsigned long long st_iter = 0, st_lanes = 0, st_solve = 0, st_slanes = 0;
+#endif
+    for (;;)
+    {
+        const lm_t pend = LM(p_op != 0);
+        const lm_t adv = LM(pos != 0) & ~pend;
+        if ((adv | pend) == 0) break;
+        if (adv != 0 && __popcll(pend) < QR_DIV_BATCH)
+        {
+            /* ---- STEP ----
+             * one 64-byte load per lane: the cell and what follows it -- the extension of a bounding-volume cell, or
+             * the next cell, which is then handled in the same round trip when the first one was culled (the walk is
+             * bound by the latency of these dependent loads, not by arithmetic) */
+#ifdef QR_STATS
+            st_iter++; st_lanes += __popcll(adv);
+#endif
+            if (lane_of(adv))
+            {
+                const u32x4 a0 = *(const QR_CONST u32x4 *)(B + pos), a1 = *(const QR_CONST u32x4 *)(B + pos + 16),
+                            b0 = *(const QR_CONST u32x4 *)(B + pos + 32), b1 = *(const QR_CONST u32x4 *)(B + pos + 48);
+                const u32 op = a0.x, srf_off = a0.y;
+                u32 next = pos + 32;
+                if (op == 0) next = 0;
+                else if (op & QR_OPT_SOLVER)
+                {
+                    if (!(op & QR_OPF_CULL) || !div_culled(a0, a1, r, dd, dde, dlen, w.tbd)) { p_op = op; p_srf = srf_off; }
+                    else if ((b0.x & QR_OPT_SOLVER) != 0)
+                    {
+                        /* second cell of the load */
+                        next = pos + 64;
+                        if (!(b0.x & QR_OPF_CULL) || !div_culled(b0, b1, r, dd, dde, dlen, w.tbd)) { p_op = b0.x; p_srf = b0.y; }
+                    }
+                }
+                else if (op & QR_OPT_BV)
+                {
+                    next = pos + 64;
+                    bool far = false;
+                    if (op & QR_OPF_CULL)
+                    {
+                        /* the array cull of walk_list: entirely behind the origin or beyond the depth bound */
+                        const float R = u2f(a1.w);
+                        const float ocx = u2f(a1.x) - r.org.x, ocy = u2f(a1.y) - r.org.y, ocz = u2f(a1.z) - r.org.z;
+                        const float bb = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+                        far = (__builtin_fmaf(R, dlen, bb) < 0.0f) | (__builtin_fmaf(-R, dlen, bb) > w.tbd);
+                    }
+                    if (far) next = a0.z;
+                    else
+                    {
+                        V3 df, ry;
+                        cell_space(B, op, srf_off, u2f(b0.x), u2f(b0.y), u2f(b0.z), r, w, df, ry);
+                        if (!bv_hit(ry, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w))) next = a0.z;
+                    }
+                }
+                else
+                {
+                    /* trnode: diff and ray in its space, cached for the surfaces behind it */
+                    const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
+                    V3 d;
+                    d.x = r.org.x - u2f(p0.x); d.y = r.org.y - u2f(p0.y); d.z = r.org.z - u2f(p0.z);
+                    w.txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
+                    w.trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, r.dir);
+                }
+                pos = next;
+            }
+        }
+        else
+        {
+            /* ---- SOLVE ---- */
+#ifdef QR_STATS
+            st_solve++; st_slanes += __popcll(pend);
+#endif
+            if (lane_of(pend))
+            {
+                SurfS s;
+                ld_surf_lane(B, p_srf, s);
+                solve_cell<SHADOW, true>(B, p_op, p_srf, s, r, dd, w, h);
+                p_op = 0;
+                if (SHADOW) { if (w.resume == 0xFFFFFFFFu) pos = 0; }
+            }
+        }
+    }
+    if (SHADOW) { if (w.resume == 0xFFFFFFFFu) occluded = true; }   /* only the lanes that walked here */
+#ifdef QR_STATS
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        atomicAdd(&stats[16], 1ull); atomicAdd(&stats[17], st_iter); atomicAdd(&stats[18], st_lanes);
+        atomicAdd(&stats[19], st_solve); atomicAdd(&stats[20], st_slanes);
+    }
+#endif
+}
+
+/*
+ * Wave-wide traversal: lanes with `active` walk their lists.  Lanes that share a list head are walked together
+ * (wave-packet walk) as long as the wave is coherent; when the leading group is a small part of what is left
+ * (many different lists: secondary hits on many small objects), or the list is a long hierarchy on which rays
+ * part ways (QR_LISTF_LONG) and the caller does not vouch for the rays' coherence (`coherent`: primary rays and
+ * the shadow rays of primary hits -- neighbouring pixels, same light), the remaining lanes whose lists allow it
+ * walk per lane.  The low bits of a list offset carry these flags (cells are 32-byte aligned).
+ */
+template <bool SHADOW>
+__device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS
                                          , unsigned long long *stats
 #endif
@@ -627,10 +869,27 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, const Ray &r, Hit
         const int leader = __ffsll((long long)pending) - 1;
         const u32 head = (u32)__builtin_amdgcn_readlane((int)r.list, leader);
         const lm_t mine = pending & LM(r.list == head);
+#ifndef QR_NO_DIV
+        const int n_left = __popcll(pending), n_mine = __popcll(mine);
+        const lm_t can_div = pending & LM((r.list & QR_LISTF_DIV) != 0);
+        const bool incoherent = n_mine * 3 <= n_left && n_left >= 12;
+        const bool long_list = !coherent && (head & QR_LISTF_LONG) != 0 && (head & QR_LISTF_DIV) != 0 && n_mine >= 4;
+        if ((incoherent || long_list) && can_div != 0)
+        {
+            const lm_t go = incoherent ? can_div : mine;
+            pending &= ~go;
+            walk_div<SHADOW>(B, lane_of(go), r, h, occluded
+#ifdef QR_STATS
+                             , stats
+#endif
+                             );
+            continue;
+        }
+#endif
         pending &= ~mine;
         if (lane_of(mine))
         {
-            walk_list<SHADOW>(B, head, r, h, occluded
+            walk_list<SHADOW>(B, head & ~31u, r, h, occluded
 #ifdef QR_STATS
                               , stats
 #endif

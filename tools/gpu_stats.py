@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Walk statistics of one snapshot with the QR_STATS build: tools/gpu_stats.py NAME [depth] (GPU box).
+"""Walk statistics of one workload with the QR_STATS build: tools/gpu_stats.py NAME|synth:N:W:H:D [depth] (GPU box).
 Build first: make -C quadray-engine_amd/csrc variant NAME=stats EXTRA=-DQR_STATS"""
 import os, sys, gzip
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,9 +8,15 @@ sys.path.insert(0, ROOT)
 import torch
 from qr_loader import load_package
 qr = load_package()
-blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", sys.argv[1] + ".qrs.gz"), "rb").read())
-scn = qr.Scene(blob)
+name = sys.argv[1]
+if name.startswith("synth:"):
+    import bench
+    blob = bench.load_blob(name)
+else:
+    blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", name + ".qrs.gz"), "rb").read())
+scn = qr.Scene(blob, rebin_tiles=name.startswith("synth:"))
 if len(sys.argv) > 2:
     scn.set_depth(int(sys.argv[2]))
-print(sys.argv[1], "depth", scn.info.depth, flush=True)
-scn.render_count()
+print(name, "depth", scn.info.depth, flush=True)
+_, c = scn.render_count()
+print(c.as_dict(), flush=True)
