@@ -16,6 +16,8 @@
  *   --snapshot F.qrs the flattened scene (include/qr_scene.h) captured through
  *                    the drop-in shim (oracle/ref_shim.cpp -> qr_capture_snapshot);
  *                    only in the binary linked with the shim (qr_ref_shim)
+ *   --animate MS     advance the scene time by MS per --bench frame (objects, lights and camera move, the
+ *                    engine rebuilds its lists: nothing can be reused from the previous frame)
  *   --bench N        wall-clock of N rt_Scene::render() calls (CPU baseline,
  *                    bench.py's cpu_baseline.kind == "reference")
  */
@@ -229,7 +231,7 @@ int main(int argc, char **argv)
     const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL;
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
-    long time_ms = 0;
+    long time_ms = 0, animate_ms = 0;
 
     for (int i = 1; i < argc; i++)
     {
@@ -248,6 +250,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--snapshot") && i + 1 < argc) snap_path = argv[++i];
         else if (!strcmp(argv[i], "--bench") && i + 1 < argc) bench = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpu")) gpu = 1;
+        else if (!strcmp(argv[i], "--animate") && i + 1 < argc) animate_ms = atol(argv[++i]);
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else { usage(); return 2; }
     }
@@ -292,7 +295,8 @@ int main(int argc, char **argv)
         printf("scene %s w %d h %d row %d t %ld fsaa %d gamma %d fresnel %d depth %d simd %dx%dv%d threads %d\n",
                scene_name, w, h, row, time_ms, fsaa, gamma, fresnel, (int)sc->depth,
                (simd & 0xFF) * 128, (simd >> 16) & 0xFF, (simd >> 8) & 0xFF, pfm->get_thnum());
-        printf("hash %016llx\n", (unsigned long long)fnv1a64_frame(frame, w, h, row));
+        const uint64_t cpu_hash = fnv1a64_frame(frame, w, h, row);      /* before --bench --animate moves the scene on */
+        printf("hash %016llx\n", (unsigned long long)cpu_hash);
 
         if (out_path != NULL)
         {
@@ -302,26 +306,10 @@ int main(int argc, char **argv)
             fclose(f);
         }
 
-        if (bench > 0)
-        {
-            std::vector<double> ms;
-            for (int i = 0; i < bench; i++)
-            {
-                double t0 = now_ms();
-                sc->render(time_ms);
-                ms.push_back(now_ms() - t0);
-            }
-            std::sort(ms.begin(), ms.end());
-            double sum = 0; for (double v : ms) sum += v;
-            printf("bench frames %d min_ms %.3f median_ms %.3f mean_ms %.3f\n",
-                   bench, ms[0], ms[ms.size() / 2], sum / ms.size());
-        }
-
         if (gpu)
         {
             /* DROP-IN TEST: same engine, same scene object, but the backend namespace occupied by
              * oracle/ref_shim.cpp -> qr_render0 -> HIP kernel.  The frame must equal the CPU SIMD frame. */
-            uint64_t cpu_hash = fnv1a64_frame(frame, w, h, row);
             int got = pfm->set_simd(simd_init(1, 8, 1));
             if (((got >> 8) & 0xFF) != 8 || (got & 0xFF) != 1)
             {
@@ -337,18 +325,56 @@ int main(int argc, char **argv)
             printf("gpu_hash %016llx shim_calls %d %s\n", (unsigned long long)gpu_hash, qr_shim_calls,
                    gpu_hash == cpu_hash ? "MATCH" : "MISMATCH");
             if (gpu_hash != cpu_hash) rc = 6;
-            if (bench > 0)
+            pfm->set_simd(simd_init(n_simd, s_type, k_size));           /* back to the engine's own backend */
+            pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+        }
+
+        long t_next = time_ms;          /* the scene time only moves forward */
+        if (bench > 0)
+        {
+            std::vector<double> ms;
+            for (int i = 0; i < bench; i++)
             {
-                std::vector<double> ms;
-                for (int i = 0; i < bench; i++)
-                {
-                    double t0 = now_ms();
-                    sc->render(time_ms);
-                    ms.push_back(now_ms() - t0);
-                }
-                std::sort(ms.begin(), ms.end());
-                printf("gpu_bench frames %d min_ms %.3f median_ms %.3f (engine update + flatten + upload + kernel + copy back)\n",
-                       bench, ms[0], ms[ms.size() / 2]);
+                double t0 = now_ms();
+                sc->render(t_next);
+                ms.push_back(now_ms() - t0);
+                t_next += animate_ms;
+            }
+            std::sort(ms.begin(), ms.end());
+            double sum = 0; for (double v : ms) sum += v;
+            printf("bench frames %d animate_ms %ld min_ms %.3f median_ms %.3f mean_ms %.3f\n",
+                   bench, animate_ms, ms[0], ms[ms.size() / 2], sum / ms.size());
+        }
+
+        if (gpu && bench > 0)
+        {
+            pfm->set_simd(simd_init(1, 8, 1));
+            pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+            std::vector<double> ms;
+            long t_last = t_next;
+            for (int i = 0; i < bench; i++)
+            {
+                double t0 = now_ms();
+                sc->render(t_next);
+                ms.push_back(now_ms() - t0);
+                t_last = t_next;
+                t_next += animate_ms;
+            }
+            std::sort(ms.begin(), ms.end());
+            printf("gpu_bench frames %d animate_ms %ld min_ms %.3f median_ms %.3f (engine update + flatten + compile + upload + kernel + copy back)\n",
+                   bench, animate_ms, ms[0], ms[ms.size() / 2]);
+            if (animate_ms != 0)
+            {
+                /* the last animated frame once more on both backends: the frames must be equal */
+                sc->render(t_last);
+                const uint64_t g = fnv1a64_frame(sc->get_frame(), w, h, sc->get_x_row());
+                pfm->set_simd(simd_init(n_simd, s_type, k_size));
+                pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
+                sc->render(t_last);
+                const uint64_t c2 = fnv1a64_frame(sc->get_frame(), w, h, sc->get_x_row());
+                printf("animated frame t %ld gpu_hash %016llx cpu_hash %016llx %s\n", t_last,
+                       (unsigned long long)g, (unsigned long long)c2, g == c2 ? "ANIM_MATCH" : "ANIM_MISMATCH");
+                if (g != c2) rc = 6;
             }
         }
 

@@ -154,15 +154,21 @@ struct Builder
 
     std::vector<uint32_t> list_off;         /* surface list head -> byte offset of its program (0 unseen)   */
     std::vector<uint32_t> light_off;        /* light list head  -> byte offset                               */
+    std::vector<uint8_t> list_heavy;        /* surface list head -> 1 holds a reflective, 2 a non-opaque surface */
     struct ClipKey { int head, trnode, cdef; uint32_t off; };
     std::vector<ClipKey> clip_memo;
     std::vector<int> chain_pos, chain_stamp; int stamp = 0;
+    /* scratch of compile_list, kept between calls (a 1080p frame compiles thousands of short tile lists) */
+    struct Tmp { int e; uint32_t op; int si; int last; bool emit; };
+    std::vector<Tmp> ch;
+    std::vector<int> lo_after, lo_self, open_arr, emit_idx;
+    std::vector<BSphere> arr_sphere;
     QrProgramStats st = {};
 
     Builder(const qr_scene_view &v_, const std::vector<qr_elem> &E_, const std::vector<BSphere> &bs_, int cm, std::vector<uint8_t> &b)
         : v(v_), E(E_), bs(bs_), cull_mode(cm), blob(b), n_srf((int)v_.hdr->n_srf), n_elm((int)E_.size())
     {
-        list_off.assign((size_t)n_elm + 1, 0); light_off.assign((size_t)n_elm + 1, 0);
+        list_off.assign((size_t)n_elm + 1, 0); light_off.assign((size_t)n_elm + 1, 0); list_heavy.assign((size_t)n_elm + 1, 0);
         chain_pos.assign((size_t)n_elm + 1, 0); chain_stamp.assign((size_t)n_elm + 1, -1);
     }
 
@@ -181,8 +187,7 @@ struct Builder
     {
         if (head == QR_NULL) return 0;
         if (list_off[head]) return list_off[head];
-        struct Tmp { int e; uint32_t op; int si; int last; bool emit; };
-        std::vector<Tmp> ch;
+        ch.clear();
         stamp++;
         for (int e = head; e != QR_NULL; e = E[e].next)
         {
@@ -190,7 +195,7 @@ struct Builder
             ch.push_back(Tmp{e, 0, E[e].simd, QR_NULL, true});
         }
         const int n = (int)ch.size();
-        std::vector<int> lo_after((size_t)n, QR_NULL), lo_self((size_t)n, QR_NULL);
+        lo_after.assign((size_t)n, QR_NULL); lo_self.assign((size_t)n, QR_NULL);
         int local_obj = QR_NULL;
         for (int i = 0; i < n; i++)
         {
@@ -253,7 +258,8 @@ struct Builder
         /* static state must not depend on whether a ray walked through an array or skipped it (AR_skp:
          * e = last; if (e == local_obj) local_obj = NULL), and arrays must nest */
         {
-            std::vector<int> open;
+            std::vector<int> &open = open_arr;
+            open.clear();
             for (int i = 0; i < n; i++)
             {
                 while (!open.empty() && open.back() < i) open.pop_back();
@@ -270,7 +276,7 @@ struct Builder
          * spheres around the first bounded member's centre.  The walk skips an array that lies entirely behind a
          * ray's origin or entirely beyond its current depth bound -- the reference's own test only asks whether the
          * LINE meets the volume.  No sphere (no cull) when a member is unbounded. */
-        std::vector<BSphere> arr_sphere((size_t)n);
+        arr_sphere.resize((size_t)n);
         if (cull_mode >= 3)
             for (int i = 0; i < n; i++)
             {
@@ -299,7 +305,7 @@ struct Builder
                 ch[i].op |= QR_OPF_CULL;
             }
         /* emit */
-        std::vector<int> emit_idx((size_t)n + 1, 0);
+        emit_idx.assign((size_t)n + 1, 0);
         int ne = 0;
         int n_emitted = 0;
         /* slot index of every cell: a bounding-volume cell takes two slots (its extension carries the volume) */
@@ -339,14 +345,23 @@ struct Builder
         /* flags in the offset's low bits: may the per-lane walk take this list, is it a long hierarchy */
         uint32_t lf = QR_LISTF_DIV;
         int n_bv = 0;
+        uint8_t heavy = 0;
         for (int i = 0; i < n; i++)
         {
+            const qr_surface &q = v.srf[ch[i].si];
+            if (is_real(q))
+                for (int k = 0; k < 2; k++)
+                {
+                    if (q.props[k] & QR_PROP_REFLECT) heavy |= 1;
+                    if (!(q.props[k] & QR_PROP_OPAQUE)) heavy |= 2;
+                }
             if (!ch[i].emit) continue;
             if (ch[i].op & QR_OPF_CLIP) lf &= ~QR_LISTF_DIV;
             if (ch[i].op & QR_OPT_BV) n_bv++;
         }
         if (n_emitted >= 96 && n_bv >= 4) lf |= QR_LISTF_LONG;
         list_off[head] = off | lf;
+        list_heavy[head] = heavy;
         return off | lf;
     }
 
@@ -439,7 +454,7 @@ struct Builder
 } // namespace
 
 int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
-                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err)
+                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks)
 {
     const int n_srf = (int)v.hdr->n_srf, n_mat = (int)v.hdr->n_mat, n_lgt = (int)v.hdr->n_lgt, n_tex = (int)v.hdr->n_texels;
     const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
@@ -449,6 +464,8 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
     if ((size_t)frm.tls_row * frm.tls_col != T.size()) { err = "tile grid does not match the tile array"; return QR_ERR_ARG; }
     try
     {
+        out.blob.reserve(sizeof(DevHeader) + (size_t)(n_srf + 1) * (sizeof(DSurf) + sizeof(DShade)) + (size_t)(n_mat + 1) * sizeof(qr_material)
+                         + (size_t)n_tex * 4 + T.size() * 4 + E.size() * 80 + (size_t)frm.frm_w * frm.frm_h / 8 + 65536);
         Builder b(v, E, bs, cull_mode, out.blob);
         /* fixed sections; index n_* is a zero record so that masked-off lanes may read it */
         b.alloc(sizeof(DevHeader), 256);
@@ -538,17 +555,7 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
          * heavy = the footprint's tile list holds a reflective or non-opaque surface: those waves can spawn
          * recursion, are started first and get issue priority */
         std::vector<uint8_t> tile_heavy(T.size(), 0);
-        for (size_t t = 0; t < T.size(); t++)
-            for (int e = T[t]; e != QR_NULL; e = E[e].next)
-            {
-                const qr_surface &q = v.srf[E[e].simd];
-                if (!is_real(q)) continue;
-                for (int k = 0; k < 2; k++)
-                {
-                    if (q.props[k] & QR_PROP_REFLECT) tile_heavy[t] |= 1;
-                    if (!(q.props[k] & QR_PROP_OPAQUE)) tile_heavy[t] |= 2;
-                }
-            }
+        for (size_t t = 0; t < T.size(); t++) tile_heavy[t] = T[t] != QR_NULL ? b.list_heavy[T[t]] : 0;
         {
             /* footprints are enumerated tile by tile (32x8 pixel groups) to keep neighbours together */
             const int gx = 32 / fw, gy = 8 / fh;
@@ -589,6 +596,35 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
             hv_ent.insert(hv_ent.end(), lt_ent.begin(), lt_ent.end());
         }
         if (out.order.size() != n_sched * 2) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
+        out.block_first.clear(); out.block_row.clear();
+        if (sched_blocks > 1)
+        {
+            /* group the schedule by horizontal block (stable: heavy footprints stay first inside a block), so that the
+             * drop-in path can launch block by block and copy block k back while block k + 1 renders */
+            const int K = std::min(sched_blocks, std::max(1, nby));
+            std::vector<std::vector<uint32_t>> part((size_t)K);
+            for (auto &pv : part) pv.reserve(out.order.size() / K + 64);
+            std::vector<int> fb((size_t)K + 1);
+            for (int k = 0; k <= K; k++) fb[k] = (int)((long long)nby * k / K);
+            std::vector<int> blk_of((size_t)nby);
+            for (int k = 0; k < K; k++) for (int y = fb[k]; y < fb[k + 1]; y++) blk_of[y] = k;
+            for (size_t i = 0; i + 1 < out.order.size(); i += 2)
+            {
+                const int by = (int)((out.order[i] >> 14) & 0x3FFFu);
+                std::vector<uint32_t> &pv = part[blk_of[by]];
+                pv.push_back(out.order[i]); pv.push_back(out.order[i + 1]);
+            }
+            size_t pos = 0;
+            for (int k = 0; k < K; k++)
+            {
+                out.block_first.push_back((uint32_t)(pos / 2));
+                out.block_row.push_back((uint32_t)std::min(fb[k] * fh, frm.frm_h));
+                std::copy(part[k].begin(), part[k].end(), out.order.begin() + pos);
+                pos += part[k].size();
+            }
+            out.block_first.push_back((uint32_t)(pos / 2));
+            out.block_row.push_back((uint32_t)frm.frm_h);
+        }
         memcpy(b.at<uint32_t>(o_ord), out.order.data(), out.order.size() * 4);
 
         DevHeader &h = *b.at<DevHeader>(0);
@@ -620,39 +656,39 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     auto in_arr = [&](uint32_t off, uint32_t base, uint32_t n, size_t sz) {
         return off >= base && (off - base) % sz == 0 && (off - base) / sz <= n && (size_t)off + sz <= limit;
     };
-    std::vector<uint8_t> seen_list(N / 32 + 1, 0);
-    /* a list program: cells inside the list area, END-terminated, array ends inside the run */
+    /* per 32-byte slot of the image: 1 = a list starts here (already checked), 2 = a cell starts here */
+    static thread_local std::vector<uint8_t> slot;
+    slot.assign(N / 32 + 1, 0);
+    /* a list program: cells inside the list area, END-terminated, array ends on cell boundaries inside the run */
     auto check_list = [&](uint32_t off) -> const char * {
         if (off == 0) return nullptr;
         if (off & 28u) return "list offset carries unknown flag bits";
         off &= ~31u;
         if (off < p.off_lists || (size_t)off + 32 > limit) return "list offset out of range";
-        if (seen_list[off / 32]) return nullptr;
-        seen_list[off / 32] = 1;
+        if (slot[off / 32] & 1) return nullptr;
+        slot[off / 32] |= 1;
         uint32_t o = off, end_cell = 0;
         for (;;)
         {
             if ((size_t)o + 32 > limit) return "list runs off the image";
             const CCell *c = (const CCell *)(b.data() + o);
+            slot[o / 32] |= 2;
             if (c->op == 0) { end_cell = o; break; }
             o += (c->op & QR_OPT_BV) ? 64 : 32;
         }
-        std::vector<uint32_t> starts;           /* an array must end on a cell boundary */
-        for (o = off; o < end_cell; o += (((const CCell *)(b.data() + o))->op & QR_OPT_BV) ? 64 : 32) starts.push_back(o);
-        starts.push_back(end_cell);
-        for (size_t k = 0; k + 1 < starts.size(); k++)
+        for (o = off; o < end_cell; )
         {
-            o = starts[k];
             const CCell *c = (const CCell *)(b.data() + o);
             const uint32_t t = c->op & QR_OPT_MASK;
             if (t == 0 || (t & (t - 1)) != 0) return "bad opcode";
             if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf)) return "cell surface offset out of range";
-            if (t == QR_OPT_BV && (c->end <= o + 32 || c->end > end_cell || !std::binary_search(starts.begin(), starts.end(), c->end)))
+            if (t == QR_OPT_BV && (c->end <= o + 32 || c->end > end_cell || (c->end & 31) || !(slot[c->end / 32] & 2)))
                 return "array end outside its list";
             if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
             if ((c->op & QR_OPF_CULL) && !(t & (QR_OPT_SOLVER | QR_OPT_BV))) return "cull flag on a cell without solver or volume";
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
             if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";
+            o += (t == QR_OPT_BV) ? 64 : 32;
         }
         return nullptr;
     };

@@ -37,13 +37,16 @@ struct QrProgram
     uint32_t off_srf = 0, off_shade = 0, off_mat = 0, off_lgt = 0, off_tex = 0, off_tiles = 0, off_lists = 0;
     uint32_t n_srf = 0, n_mat = 0, n_lgt = 0, n_tex = 0, n_tiles = 0;
     QrProgramStats stats = {};
+    /* sched_blocks > 1: the schedule is grouped by horizontal block of the frame (heavy footprints first inside
+     * every block); entries [block_first[k], block_first[k+1]) render rows [block_row[k], block_row[k+1]) */
+    std::vector<uint32_t> block_first, block_row;
 };
 
 int  qr_snapshot_validate(const qr_scene_view &v, std::string &err);
 void qr_bound_spheres(const qr_scene_view &v, std::vector<BSphere> &out);
 /* E / T: list cells and tile heads (the snapshot's, or the ones the binning pass built); frm: frame record to use */
 int  qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
-                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err);
+                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks = 0);
 int  qr_program_verify(const QrProgram &p, std::string &err);
 
 #endif /* QR_INTERNAL_H */

@@ -118,6 +118,37 @@ def test_gpu_drop_in_through_reference_engine():
         assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
 
 
+def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
+    """BASELINE's headline configuration through the actual boundary: the unmodified engine renders demo scene 1 at
+    1920x1080 with its own backend and through qr_render0, frozen and animated (33 ms per frame: the engine
+    rebuilds every list, nothing can be reused); frames must match; the per-call split is printed."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/qr_ref_shim was not built (needs /root/reference at build time)")
+    tmp = tempfile.mkdtemp(prefix="qrdropb_")
+    os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
+    report = []
+    for extra in ([], ["--animate", "33"]):
+        out = subprocess.run([exe, "--scene", "demo01", "-w", "1920", "-h", "1080", "--gpu", "--bench", "50"] + extra,
+                             cwd=tmp, capture_output=True, text=True, timeout=600, env=dict(os.environ, QR_VERBOSE="1"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
+        if extra:
+            assert "ANIM_MATCH" in out.stdout, out.stdout
+        line = [l for l in out.stdout.splitlines() if l.startswith("gpu_bench")][0]
+        cpu = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0]
+        split = [l for l in out.stderr.splitlines() if l.startswith("qr_render0:")][-1]
+        report += [cpu, line, split]
+        assert float(re.search(r"median_ms ([0-9.]+)", line).group(1)) < 5.0
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+
+
 @pytest.mark.parametrize("name", SMALL_CASES + BIG_CASES)
 def test_gpu_tile_binning_keeps_frames(qr, name):
     """QR_UPLOAD_REBIN_TILES: tile lists rebuilt on the GPU from the camera list (replaces the engine's
