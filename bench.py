@@ -105,7 +105,10 @@ def load_blob(name):
             spec = importlib.util.spec_from_file_location("qr_synth", os.path.join(ROOT, "quadray-engine_amd", "synth.py"))
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            _SYNTH_CACHE[name] = mod.make_scene(n_objects=n, width=w, height=h, depth=d)
+            # the generator writes the global hierarchical list only; per-object shadow lists come from the product's
+            # list-building pass (qr_snapshot_build_lists_c: the role of the engine's ssort / lsort)
+            from qr_loader import load_package
+            _SYNTH_CACHE[name] = load_package().build_lists(mod.make_scene(n_objects=n, width=w, height=h, depth=d, shadow_lists=False))
         return _SYNTH_CACHE[name]
     with open(os.path.join(ROOT, "tests", "golden", name + ".qrs.gz"), "rb") as f:
         return gzip.decompress(f.read())
@@ -209,6 +212,8 @@ def main():
     ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="steps (frames per GPU) in flight, each on its own streams")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: gather every frame on rank 0 (north_star's wording) instead of frame f on rank f")
     args = ap.parse_args()
 
     import torch
@@ -270,6 +275,7 @@ def main():
     comm = torch.cuda.Stream()
     frames = [[scn.new_frame() for _ in range(N)] for _ in range(B)]    # render targets of the steps in flight
     finals = [scn.new_frame() for _ in range(B)]                        # the frame this rank assembles
+    gfinals = [[scn.new_frame() for _ in range(N)] for _ in range(B)] if (args.gather and rank == 0 and N > 1) else None
     ev_render = [torch.cuda.Event() for _ in range(B)]
     ev_comm = [torch.cuda.Event() for _ in range(2)]                    # per group of D steps
     # the N blocks this rank owns in a step (block (rank + f) mod N of frame f) go out as ONE multi-target
@@ -285,7 +291,10 @@ def main():
             with torch.cuda.stream(comm):
                 for b in state["pending"]:
                     comm.wait_event(ev_render[b])
-                ex.exchange_many([(frames[b], finals[b]) for b in state["pending"]])
+                if args.gather:
+                    ex.gather_many([(frames[b], gfinals[b] if gfinals else None) for b in state["pending"]], root=0)
+                else:
+                    ex.exchange_many([(frames[b], finals[b]) for b in state["pending"]])
                 ev_comm[grp].record(comm)
             state["pending"] = []
 
@@ -329,7 +338,11 @@ def main():
     ok = True
     if N > 1:
         # the assembled frame must equal a whole-frame render of this rank (which passed the gate above)
-        ok = bool((gate == finals[(args.steps - 1) % B]).all().item())
+        last = (args.steps - 1) % B
+        if args.gather:
+            ok = all(bool((gate == g).all().item()) for g in gfinals[last]) if rank == 0 else True
+        else:
+            ok = bool((gate == finals[last]).all().item())
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
@@ -347,7 +360,8 @@ def main():
         devs = [None] * N
         dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}")
         collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": devs,
-                      "pattern": "grouped point-to-point all-to-all of row blocks, one per step group (sharding.py)"}
+                      "pattern": ("grouped point-to-point gather of row blocks to rank 0" if args.gather else
+                                  "grouped point-to-point all-to-all of row blocks") + ", one call per step group (sharding.py)"}
 
     # dominant-kernel duration: HIP events recorded on the launch stream around full-frame launches
     scn.set_rows(0, H, 0, 1)

@@ -136,6 +136,15 @@ typedef struct qr_program_info
     uint32_t reserved[3];
 } qr_program_info;
 int qr_program_stats(const void *blob, uint64_t size, qr_program_info *info);
+
+/*
+ * Host-only: build per-surface shadow, reflection / refraction and light lists for a snapshot that carries one
+ * global surface list (qr_frame.clist) -- the role of rt_SceneThread::ssort / lsort (engine.cpp:2134-2753) with
+ * their bbox_shad / bbox_side culling (rtgeom.cpp:1004, 1954), from the surfaces' conservative bounds.  Lists
+ * only cull: frames are unchanged.  Returns a NEW snapshot (release with qr_free) whose surfaces point at the
+ * new lists; the global list's order, bounding-volume arrays and trnode markers are preserved in every list.
+ */
+int qr_snapshot_build_lists_c(const void *blob, uint64_t size, void **out_blob, uint64_t *out_size);
 int qr_scene_get_info(const qr_device_scene *scn, qr_scene_info *info);
 
 /* Override recursion depth (s_inf->depth, tracer.h:173) of an uploaded scene. */

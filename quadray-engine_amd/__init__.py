@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR
 # every symbol include/qrhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
-    "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
+    "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_snapshot_build_lists_c", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
     "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
@@ -84,6 +84,8 @@ def lib():
     L.qr_scene_upload_ex.argtypes = [vp, cu64, ci, ctypes.c_uint32, ctypes.POINTER(vp)]
     L.qr_scene_destroy.argtypes = [vp]
     L.qr_program_stats.argtypes = [vp, cu64, ctypes.POINTER(ProgramInfo)]
+    L.qr_snapshot_build_lists_c.argtypes = [vp, cu64, ctypes.POINTER(vp), ctypes.POINTER(cu64)]
+    L.qr_free.argtypes = [vp]
     L.qr_frame_hash.argtypes = [vp, cu64]
     L.qr_frame_hash.restype = cu64
     L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
@@ -119,6 +121,17 @@ def frame_hash(frame):
         frame = frame.cpu().numpy()
     f = np.ascontiguousarray(frame).view(np.uint32)
     return int(lib().qr_frame_hash(f.ctypes.data_as(ctypes.c_void_p), f.size))
+
+
+def build_lists(blob):
+    """Per-surface shadow / reflection / light lists from the global list (host pass, no GPU): returns a new snapshot."""
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    _check(lib().qr_snapshot_build_lists_c(buf, len(blob), ctypes.byref(out), ctypes.byref(n)))
+    try:
+        return ctypes.string_at(out, n.value)
+    finally:
+        lib().qr_free(out)
 
 
 def program_stats(blob):

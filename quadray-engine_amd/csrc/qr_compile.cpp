@@ -778,3 +778,265 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
     info->n_dropped = p.stats.n_dropped; info->n_clip_cells = p.stats.n_clip_cells; info->n_sched = p.n_sched;
     return QR_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* per-surface list building (the role of rt_SceneThread::ssort / lsort, engine.cpp:2134-2753)             */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/*
+ * For scenes that arrive with one global surface list only (scenes the reference engine did not prepare: the
+ * synthetic 10k-quadric scene, user scenes), build what the engine's ssort / lsort build with their bounding-box
+ * predicates (bbox_shad rtgeom.cpp:1004, bbox_side rtgeom.cpp:1954):
+ *   - per surface and light a SHADOW list: the members of the global list that can stand between the light
+ *     and the surface -- here: whose conservative bounding sphere (qr_bounds.hpp) meets the hull of the light's
+ *     position and the surface's bounding sphere;
+ *   - per surface side a REFLECTION / REFRACTION list: for an untransformed plane the members that reach into
+ *     the half-space that side faces; everything for other shapes (what the engine does for them too);
+ *   - light lists: every light, with its shadow list.
+ * Lists only cull (a shorter list must not change any pixel), so the predicates are our own conservative ones, not
+ * the engine's box arithmetic.  The global list's ORDER and STRUCTURE are kept: members keep their relative order,
+ * a bounding-volume or trnode element stays in front of its first kept member with `data` patched to the last
+ * kept one -- the format the walk (and the reference) expects.  Arrays whose union sphere fails the predicate are
+ * pruned without visiting their members.  Output: a new snapshot.
+ */
+#ifndef QR_FLAT_LIST_MAX
+#define QR_FLAT_LIST_MAX 128
+#endif
+
+namespace {
+
+struct ListFilter
+{
+    const qr_scene_view &v;
+    const std::vector<BSphere> &bs;
+    std::vector<qr_elem> &E;                /* grows */
+    struct Node { int e; int si; int last; bool head; BSphere bound; bool bounded; };
+    std::vector<Node> ch;
+
+    ListFilter(const qr_scene_view &v_, const std::vector<BSphere> &bs_, std::vector<qr_elem> &E_, int clist)
+        : v(v_), bs(bs_), E(E_)
+    {
+        std::vector<int> pos_of((size_t)v.hdr->n_elm, -1);
+        for (int e = clist; e != QR_NULL; e = v.elm[e].next) { pos_of[e] = (int)ch.size(); ch.push_back(Node{e, v.elm[e].simd, -1, false, {}, false}); }
+        const int n = (int)ch.size();
+        for (int i = 0; i < n; i++)
+        {
+            const qr_elem &el = v.elm[ch[i].e];
+            const qr_surface &s = v.srf[el.simd];
+            const bool head = (el.kind & 3) == 1 || s.srf_t[3] < 0;
+            ch[i].head = head && el.data != QR_NULL && pos_of[el.data] >= i;
+            if (ch[i].head) ch[i].last = pos_of[el.data];
+            else { ch[i].bound = bs[el.simd]; ch[i].bounded = is_real(s) && bs[el.simd].r < 1e18f; }
+        }
+        /* union spheres of arrays, innermost first (a later head nests inside an earlier one) */
+        for (int i = n - 1; i >= 0; i--)
+        {
+            if (!ch[i].head) continue;
+            bool ok = true; int first = -1;
+            for (int k = i + 1; k <= ch[i].last; k++)
+                if (!ch[k].head) { if (!is_real(v.srf[ch[k].si])) continue; if (!ch[k].bounded) ok = false; else if (first < 0) first = k; }
+            ch[i].bounded = false;
+            if (!ok || first < 0) continue;
+            const BSphere &c0 = ch[first].bound;
+            double R = 0.0;
+            for (int k = i + 1; k <= ch[i].last; k++)
+                if (!ch[k].head && ch[k].bounded)
+                {
+                    const BSphere &m = ch[k].bound;
+                    const double dx = (double)m.c[0] - c0.c[0], dy = (double)m.c[1] - c0.c[1], dz = (double)m.c[2] - c0.c[2];
+                    const double d = __builtin_sqrt(dx * dx + dy * dy + dz * dz) + (double)m.r;
+                    if (d > R) R = d;
+                }
+            ch[i].bound = c0; ch[i].bound.r = (float)(R * 1.0001 + 1e-4);
+            ch[i].bounded = true;
+        }
+    }
+
+    /* keep(sphere, bounded) -> may a surface with this bound matter; returns the new list's head */
+    template <typename Pred>
+    int filter(Pred keep)
+    {
+        struct Open { int idx; int out; int last; };
+        std::vector<Open> open;
+        int head = QR_NULL, tail = QR_NULL;
+        auto emit = [&](int src_e, int data) {
+            qr_elem c = v.elm[src_e];
+            c.data = data; c.next = QR_NULL;
+            E.push_back(c);
+            const int ix = (int)E.size() - 1;
+            if (tail != QR_NULL) E[tail].next = ix; else head = ix;
+            tail = ix;
+            return ix;
+        };
+        auto close_until = [&](int i) {
+            while (!open.empty() && open.back().last < i)
+            {
+                if (open.back().out != QR_NULL) E[open.back().out].data = tail;      /* last kept member */
+                open.pop_back();
+            }
+        };
+        const int n = (int)ch.size();
+        for (int i = 0; i < n; )
+        {
+            close_until(i);
+            const Node &nd = ch[i];
+            if (nd.head)
+            {
+                if (nd.bounded && !keep(nd.bound, true)) { i = nd.last + 1; continue; }      /* prune the array */
+                open.push_back(Open{i, QR_NULL, nd.last});
+                i++;
+                continue;
+            }
+            const bool real = is_real(v.srf[nd.si]);
+            if (!real || keep(nd.bound, nd.bounded))
+            {
+                for (Open &o : open) if (o.out == QR_NULL) o.out = emit(ch[o.idx].e, QR_NULL);
+                emit(nd.e, v.elm[nd.e].data);
+            }
+            i++;
+        }
+        close_until(n);
+        /* a list that keeps only a handful of surfaces does not need their bounding-volume elements (AR_ptr elements
+         * only skip work, tracer.cpp:3955-4054): written flat it is a fraction of the cells.  Trnode elements stay. */
+        int kept = 0;
+        for (int e = head; e != QR_NULL; e = E[e].next) if (is_real(v.srf[E[e].simd])) kept++;
+        if (kept <= QR_FLAT_LIST_MAX)
+        {
+            int nh = QR_NULL, nt = QR_NULL;
+            for (int e = head; e != QR_NULL; )
+            {
+                const int nx = E[e].next;
+                if ((E[e].kind & 3) != 1)
+                {
+                    if (nt != QR_NULL) E[nt].next = e; else nh = e;
+                    nt = e; E[e].next = QR_NULL;
+                }
+                e = nx;
+            }
+            head = nh;
+        }
+        return head;
+    }
+};
+
+} // namespace
+
+int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, std::string &err)
+{
+    int rc = qr_snapshot_validate(v, err);
+    if (rc != QR_OK) return rc;
+    const qr_frame &fr = *v.frame;
+    if (fr.clist == QR_NULL) { err = "snapshot has no global list (clist)"; return QR_ERR_ARG; }
+    std::vector<BSphere> bs;
+    qr_bound_spheres(v, bs);
+    const int n_srf = (int)v.hdr->n_srf, n_lgt = (int)v.hdr->n_lgt;
+    std::vector<qr_elem> E(v.elm, v.elm + v.hdr->n_elm);
+    std::vector<qr_surface> S(v.srf, v.srf + n_srf);
+    ListFilter lf(v, bs, E, fr.clist);
+
+    for (int i = 0; i < n_srf; i++)
+    {
+        qr_surface &s = S[i];
+        if (!is_real(s)) continue;
+        const BSphere &sb = bs[i];
+        const bool s_bounded = sb.r < 1e18f;
+        /* reflection / refraction lists per side */
+        int side_list[2] = { fr.clist, fr.clist };
+        if (s.srf_t[0] == 1 && s.has_trm == 0)
+        {
+            const int k = (int)((s.axes >> 4) & 3);
+            const double sg = ((s.axes >> 10) & 1) ? -1.0 : 1.0;
+            for (int side = 0; side < 2; side++)
+            {
+                /* side 0 (outer) is hit by rays travelling against the signed axis: it faces +sg along k */
+                const double face = side == 0 ? sg : -sg;
+                side_list[side] = lf.filter([&](const BSphere &x, bool bounded) {
+                    if (!bounded) return true;
+                    return ((double)x.c[k] - (double)s.pos[k]) * face + (double)x.r * 1.001 + 1e-3 >= 0.0;
+                });
+            }
+        }
+        s.lst[1] = side_list[0]; s.lst[3] = side_list[1];
+        /* light list with per-light shadow lists (shared by both sides) */
+        int l_head = QR_NULL, l_tail = QR_NULL;
+        for (int l = 0; l < n_lgt; l++)
+        {
+            int shadow = fr.clist;
+            if (s_bounded)
+            {
+                const double lp[3] = { v.lgt[l].pos[0], v.lgt[l].pos[1], v.lgt[l].pos[2] };
+                const double D[3] = { sb.c[0] - lp[0], sb.c[1] - lp[1], sb.c[2] - lp[2] };
+                const double D2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2], Dl = __builtin_sqrt(D2);
+                const double rho = Dl > 0.0 ? (double)sb.r / Dl : 2.0;
+                if (rho < 0.95)
+                {
+                    /* hull of the light position and the surface's sphere: at parameter tau in [0,1] along the axis a
+                     * sphere of radius tau r_s; a sphere (c, r_x) meets it iff min_tau |c - axis(tau)| - tau r_s <= r_x;
+                     * the minimum is at least d_min sqrt(1 - rho^2) - tc r_s with d_min the distance to the axis
+                     * segment and tc its parameter */
+                    const double shrink = __builtin_sqrt(1.0 - rho * rho);
+                    shadow = lf.filter([&](const BSphere &x, bool bounded) {
+                        if (!bounded) return true;
+                        const double P[3] = { x.c[0] - lp[0], x.c[1] - lp[1], x.c[2] - lp[2] };
+                        const double t = (P[0] * D[0] + P[1] * D[1] + P[2] * D[2]) / D2;
+                        const double tc = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                        const double q[3] = { P[0] - tc * D[0], P[1] - tc * D[1], P[2] - tc * D[2] };
+                        const double dmin = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                        const double xr = (double)x.r * 1.001 + 1e-3;
+                        if (t > 1.0 + ((double)sb.r + xr) / Dl + 1e-3) return false;        /* behind the surface */
+                        return dmin * shrink <= xr + tc * (double)sb.r * 1.001 + 1e-3;
+                    });
+                }
+            }
+            qr_elem c; c.simd = l; c.data = shadow; c.next = QR_NULL; c.kind = 0;
+            E.push_back(c);
+            const int ix = (int)E.size() - 1;
+            if (l_tail != QR_NULL) E[l_tail].next = ix; else l_head = ix;
+            l_tail = ix;
+        }
+        s.lst[0] = l_head; s.lst[2] = l_head;
+    }
+
+    /* serialise the new snapshot: same sections, larger element array */
+    qr_header h = *v.hdr;
+    auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off = a16(sizeof(qr_header));
+    h.header_bytes = sizeof(qr_header);
+    h.off_frame = (uint32_t)off;  off = a16(off + sizeof(qr_frame));
+    h.off_srf = (uint32_t)off;    off = a16(off + (size_t)n_srf * sizeof(qr_surface));
+    h.off_mat = (uint32_t)off;    off = a16(off + (size_t)h.n_mat * sizeof(qr_material));
+    h.off_lgt = (uint32_t)off;    off = a16(off + (size_t)h.n_lgt * sizeof(qr_light));
+    h.off_elm = (uint32_t)off;    off = a16(off + E.size() * sizeof(qr_elem));
+    h.off_tiles = (uint32_t)off;  off = a16(off + (size_t)h.n_tiles * 4);
+    h.off_texels = (uint32_t)off; off = a16(off + (size_t)h.n_texels * 4);
+    if (off > 0xFFFFFFFFull) { err = "snapshot exceeds 4 GiB"; return QR_ERR_NOMEM; }
+    h.n_elm = (uint32_t)E.size();
+    h.total_bytes = (uint32_t)off;
+    out.assign(off, 0);
+    memcpy(out.data(), &h, sizeof(h));
+    memcpy(out.data() + h.off_frame, v.frame, sizeof(qr_frame));
+    memcpy(out.data() + h.off_srf, S.data(), S.size() * sizeof(qr_surface));
+    if (h.n_mat) memcpy(out.data() + h.off_mat, v.mat, (size_t)h.n_mat * sizeof(qr_material));
+    if (h.n_lgt) memcpy(out.data() + h.off_lgt, v.lgt, (size_t)h.n_lgt * sizeof(qr_light));
+    memcpy(out.data() + h.off_elm, E.data(), E.size() * sizeof(qr_elem));
+    if (h.n_tiles) memcpy(out.data() + h.off_tiles, v.tiles, (size_t)h.n_tiles * 4);
+    if (h.n_texels) memcpy(out.data() + h.off_texels, v.texels, (size_t)h.n_texels * 4);
+    return QR_OK;
+}
+
+extern "C" int qr_snapshot_build_lists_c(const void *blob, uint64_t size, void **out_blob, uint64_t *out_size)
+{
+    if (blob == nullptr || out_blob == nullptr || out_size == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    qr_scene_view v;
+    const int rc0 = qr_scene_view_init(&v, blob, size);
+    if (rc0 != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc0) + ")");
+    std::vector<uint8_t> out;
+    std::string err;
+    const int rc = qr_snapshot_build_lists(v, out, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    void *p = malloc(out.size());
+    if (p == nullptr) return qr_fail(QR_ERR_NOMEM, "out of memory");
+    memcpy(p, out.data(), out.size());
+    *out_blob = p; *out_size = out.size();
+    return QR_OK;
+}

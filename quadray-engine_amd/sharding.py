@@ -88,3 +88,48 @@ class FrameExchange:
                 req.wait()
         for host, dev in recv_host:
             dev.copy_(host)
+
+    def gather_many(self, steps, root=0, group=None):
+        """Gather mode ("final image gathered", BASELINE.json north_star): every frame of every step ends complete
+        on rank `root` instead of frame f on rank f -- what a display or a file writer on one rank needs.
+        `steps` = [(frames, finals)], finals = list of `world` [h,w] tensors on the root (ignored elsewhere).
+        One grouped send/recv for all steps; the root receives (world - 1) / world of every frame, so this
+        mode is bound by the root's links (7 x 153 GB/s xGMI in an 8-GPU node) where the all-to-all of
+        exchange_many spreads the traffic over all links."""
+        world, rank, lo = self.world, self.rank, self.lo
+        if world == 1:
+            for frames, finals in steps:
+                finals[0].copy_(frames[0])
+            return
+        staged = steps[0][0][0].is_cuda and dist.get_backend(group) == "gloo"
+        if staged:
+            torch.cuda.current_stream().synchronize()
+        recv_host, ops, keep = [], [], []
+        for frames, finals in steps:
+            for f in range(world):
+                if rank == root:
+                    for peer in range(world):
+                        b = block_of(peer, f, world)
+                        dst = finals[f][lo[b]:lo[b + 1]]
+                        if peer == root:
+                            dst.copy_(frames[f][lo[b]:lo[b + 1]])
+                            continue
+                        if staged:
+                            recv_host.append((torch.empty(dst.shape, dtype=dst.dtype), dst))
+                            dst = recv_host[-1][0]
+                        if dst.numel():
+                            ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+                        keep.append(dst)
+                else:
+                    b = block_of(rank, f, world)
+                    src = frames[f][lo[b]:lo[b + 1]]
+                    if staged:
+                        src = src.cpu()
+                    if src.numel():
+                        ops.append(dist.P2POp(dist.isend, src, root, group))
+                    keep.append(src)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for host, dev in recv_host:
+            dev.copy_(host)

@@ -44,6 +44,13 @@ def main():
     ex.exchange_many(steps)
     for s, (_, fin) in enumerate(steps):
         ok = ok and bool(((fin ^ s).numpy().view(np.uint32) == whole).all())
+    # gather mode: every frame complete on rank 0
+    gfin = [torch.zeros((h, w), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    ex.gather_many([(frames, gfin)], root=0)
+    if rank == 0:
+        for f in range(world):
+            wf, _, _ = qr_oracle.render(blob, depth=f, threads=1)
+            ok = ok and bool((gfin[f].numpy().view(np.uint32) == wf).all())
     # every row of every frame is rendered by exactly one rank
     cover = torch.zeros((world, h), dtype=torch.int32)
     for f in range(world):

@@ -43,11 +43,13 @@ def test_synth_scene_is_deterministic_and_bounding_volumes_are_conservative(orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lists", ["generator", "built"])
 @pytest.mark.parametrize("cfg", [SMALL, MID], ids=["300obj_320x240", "2000obj_384x216_aa4_gamma"])
-def test_gpu_synth_scene_matches_oracle(qr, oracle, cfg):
-    """No tile lists in the snapshot: the backend bins them on the GPU, then must match the oracle."""
+def test_gpu_synth_scene_matches_oracle(qr, oracle, cfg, lists):
+    """No tile lists in the snapshot: the backend bins them on the GPU, then must match the oracle.  Per-object shadow
+    lists either from the generator or built by the product's pass from the global list (what bench.py uses)."""
     import torch
-    blob = _synth().make_scene(**cfg)
+    blob = _synth().make_scene(**cfg) if lists == "generator" else qr.build_lists(_synth().make_scene(shadow_lists=False, **cfg))
     scn = qr.Scene(blob, rebin_tiles=True)
     assert scn.info.n_tiles > 1
     frame = scn.new_frame(); ids = torch.full_like(frame, -2)
@@ -71,7 +73,7 @@ def test_gpu_synth_10k_full_size_properties(qr):
     oracle, so size-independent properties: tile-row shards compose to the whole frame bit-exactly, two
     tile sizes of the binning pass agree, and a 1/16-scale render equals the oracle-checked path's."""
     import torch
-    blob = _synth().make_scene()
+    blob = qr.build_lists(_synth().make_scene(shadow_lists=False))      # config 5 as bench.py renders it
     scn = qr.Scene(blob, rebin_tiles=True)
     whole = scn.render(); torch.cuda.synchronize()
     assert int((whole != 0).sum().item()) > whole.numel() // 4
