@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Assemble profiles/ from one tools/gpu_profile_round.sh run: tools/make_profiles.py TAG [ROUND]
-(reads gpurun_out/TAG_*, writes profiles/<ROUND>_final_demo1_1080p.txt, <ROUND>_bench_n1.json, traffic.json, valu.json)."""
-import csv, glob, json, os, sys, collections
+"""Assemble profiles/ from one tools/gpu_profile_round.sh run: tools/make_profiles.py TAG ROUND
+(reads gpurun_out/TAG_*, writes profiles/<ROUND>_*.txt / .json and profiles/counters.json)."""
+import csv, glob, json, os, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles")
 KERN = "qr_render_kernel<false"
+git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+
 
 def counters(d):
     acc = collections.defaultdict(list)
@@ -15,44 +17,88 @@ def counters(d):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
+
 def kernel_stats(d):
     for f in glob.glob(os.path.join(G, d, "**", "*_kernel_stats.csv"), recursive=True):
         return [l.rstrip("\n") for l in open(f)][:3]
     return []
 
-bench = open(os.path.join(G, f"{tag}_bench_n1.json")).read().strip()
+
+def overlap(d):
+    """From the kernel trace: how many render dispatches are in flight at once (dispatch intervals overlap)."""
+    iv = []
+    for f in glob.glob(os.path.join(G, d, "**", "*_kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERN in r["Kernel_Name"]:
+                iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    iv.sort()
+    if len(iv) < 10:
+        return None
+    iv = iv[len(iv) // 10:]                      # skip warm-up
+    ev = sorted([(s, 1) for s, _ in iv] + [(e, -1) for _, e in iv])
+    cur = 0; t_prev = ev[0][0]; hist = collections.Counter()
+    for t, dlt in ev:
+        hist[cur] += t - t_prev; t_prev = t; cur += dlt
+    tot = sum(v for k, v in hist.items() if k > 0)
+    span = iv[-1][1] - iv[0][0]
+    dur = sum(e - s for s, e in iv) / len(iv)
+    return dict(dispatches=len(iv), mean_dispatch_us=dur / 1e3, span_per_dispatch_us=span / len(iv) / 1e3,
+                time_with_n_in_flight={str(k): round(v / tot, 3) for k, v in sorted(hist.items()) if k > 0})
+
+
+bench = open(os.path.join(G, f"{tag}_bench_n1.json")).read().strip().splitlines()[-1]
 open(os.path.join(P, f"{rnd}_bench_n1.json"), "w").write(bench + "\n")
 b = json.loads(bench)
+
+out = [f"# {rnd} profile of the BASELINE metric workload demo1_1080p, default build, git {git}\n",
+       "# tools/gpu_profile_round.sh on one MI355X: rocprofv3 --kernel-trace --stats (serial launches, --inflight 1), separate --pmc passes;\n",
+       "# per-launch means over the qr_render_kernel<false,4> dispatches\n\n"]
+out += [l + "\n" for l in kernel_stats(f"{tag}_trace_serial")]
 c = {}
-for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ1", "pmc_SQ2"):
+for d in ("pmc_FETCH_SIZE_demo1_1080p", "pmc_WRITE_SIZE_demo1_1080p", "pmc_SQ_demo1_1080p", "pmc_SQ1_demo1_1080p"):
     c.update(counters(f"{tag}_{d}"))
-out = [f"# {rnd} final profile, demo1_1080p (BASELINE metric workload), default build\n",
-       "# tools/gpu_profile_round.sh on one MI355X: bench.py; rocprofv3 --kernel-trace --stats; separate --pmc passes\n",
-       "# (FETCH_SIZE, WRITE_SIZE, two SQ passes); per-launch means over the qr_render_kernel<false,4> dispatches\n\n"]
-out += [l + "\n" for l in kernel_stats(f"{tag}_trace")]
 out.append("\n")
 for k in sorted(c):
     out.append(f"{k:28s} {c[k]:18.1f}\n")
 out.append(f"\n# bench.py line of the same run (HIP-event kernel time {b['roofline']['kernel_avg_ms']*1e3:.1f} us)\n{bench}\n")
 open(os.path.join(P, f"{rnd}_final_demo1_1080p.txt"), "w").write("".join(out))
-tr = json.load(open(os.path.join(P, "traffic.json")))
-if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-    tr["demo1_1080p"] = {"fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
-                         "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
-    json.dump(tr, open(os.path.join(P, "traffic.json"), "w"), indent=1)
-if "SQ_WAVE_CYCLES" in c and "SQ_INSTS_VALU" in c:
-    va = json.load(open(os.path.join(P, "valu.json")))
-    w = c["SQ_WAVE_CYCLES"]
-    va["demo1_1080p"] = dict(insts_valu=c["SQ_INSTS_VALU"], insts_salu=c["SQ_INSTS_SALU"], insts_smem=c["SQ_INSTS_SMEM"],
-                             waves=c.get("SQ_WAVES"), lane_utilisation=c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_INSTS_VALU"]),
-                             wave_active_frac=c["SQ_ACTIVE_INST_ANY"] / w, wave_wait_frac=c["SQ_WAIT_ANY"] / w,
-                             wave_issue_stall_frac=c["SQ_WAIT_INST_ANY"] / w,
-                             valu_issue_quadcycles_per_simd=c["SQ_ACTIVE_INST_VALU"] / 1024,
-                             source=f"profiles/{rnd}_final_demo1_1080p.txt")
-    json.dump(va, open(os.path.join(P, "valu.json"), "w"), indent=1, sort_keys=True)
+
+ov = overlap(f"{tag}_trace_inflight3")
+o2 = [f"# {rnd} kernel trace of the DEFAULT bench mode (three steps in flight, one HIP stream each), git {git}\n",
+      "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline\n\n"]
+o2 += [l + "\n" for l in kernel_stats(f"{tag}_trace_inflight3")]
+o2.append("\n# dispatch intervals of qr_render_kernel<false,4> from the trace (Start/End timestamps):\n")
+o2.append(json.dumps(ov, indent=1) + "\n")
+o2.append("# mean_dispatch_us = duration of one launch while others run beside it; span_per_dispatch_us = wall time per frame;\n"
+          "# time_with_n_in_flight = share of the busy time with n render dispatches executing at once\n")
+open(os.path.join(P, f"{rnd}_kernel_trace_inflight3.txt"), "w").write("".join(o2))
+
+cj = {}
+for w in ("demo1_1080p", "demo1_1080p_d0", "demo2_1080p_gf_d3", "demo2_2160p_aa4", "synth10k_4320p"):
+    cc = {}
+    for d in (f"pmc_FETCH_SIZE_{w}", f"pmc_WRITE_SIZE_{w}", f"pmc_SQ_{w}"):
+        cc.update(counters(f"{tag}_{d}"))
+    if "SQ_INSTS_VALU" not in cc:
+        continue
+    e = dict(insts_valu=cc["SQ_INSTS_VALU"], insts_salu=cc["SQ_INSTS_SALU"], insts_smem=cc["SQ_INSTS_SMEM"],
+             insts_vmem_rd=cc.get("SQ_INSTS_VMEM_RD"), insts_vmem_wr=cc.get("SQ_INSTS_VMEM_WR"),
+             waves=cc.get("SQ_WAVES"), wave_cycles=cc.get("SQ_WAVE_CYCLES"),
+             lane_utilisation=cc["SQ_THREAD_CYCLES_VALU"] / (64 * cc["SQ_INSTS_VALU"]) if cc.get("SQ_THREAD_CYCLES_VALU") else None,
+             source=f"profiles/{rnd}_counters_all_workloads.txt (rocprofv3 --pmc passes of tools/gpu_profile_round.sh)", git=git)
+    if "FETCH_SIZE" in cc and "WRITE_SIZE" in cc:
+        # MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> doubled; both in KiB
+        e.update(fetch_size_kib=cc["FETCH_SIZE"], write_size_kib=cc["WRITE_SIZE"],
+                 hbm_bytes_per_launch=int((2 * cc["FETCH_SIZE"] + cc["WRITE_SIZE"]) * 1024))
+    cj[w] = e
+json.dump(cj, open(os.path.join(P, "counters.json"), "w"), indent=1, sort_keys=True)
+lines = [f"# {rnd} per-launch hardware counters of qr_render_kernel<false,4>, all workloads, git {git} (tools/gpu_profile_round.sh)\n"]
+for w, e in cj.items():
+    lines.append(w + ": " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in e.items() if k not in ("source", "git")) + "\n")
+open(os.path.join(P, f"{rnd}_counters_all_workloads.txt"), "w").write("".join(lines))
+
 import shutil
 for f in glob.glob(os.path.join(G, f"{tag}_bench_*.json")):
     name = os.path.basename(f)[len(tag) + 1:]
     if name != "bench_n1.json" and os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(P, f"{rnd}_{name}"))
-print("".join(out[:12]))
+print("".join(out[:14])); print("".join(o2))
