@@ -164,6 +164,7 @@ struct Builder
     std::vector<int> lo_after, lo_self, open_arr, emit_idx;
     std::vector<BSphere> arr_sphere;
     QrProgramStats st = {};
+    bool any_long = false;
 
     Builder(const qr_scene_view &v_, const std::vector<qr_elem> &E_, const std::vector<BSphere> &bs_, int cm, std::vector<uint8_t> &b)
         : v(v_), E(E_), bs(bs_), cull_mode(cm), blob(b), n_srf((int)v_.hdr->n_srf), n_elm((int)E_.size())
@@ -359,7 +360,7 @@ struct Builder
             if (ch[i].op & QR_OPF_CLIP) lf &= ~QR_LISTF_DIV;
             if (ch[i].op & QR_OPT_BV) n_bv++;
         }
-        if (n_emitted >= 96 && n_bv >= 4) lf |= QR_LISTF_LONG;
+        if (n_emitted >= 96 && n_bv >= 4) { lf |= QR_LISTF_LONG; any_long = true; }
         list_off[head] = off | lf;
         list_heavy[head] = heavy;
         return off | lf;
@@ -637,6 +638,7 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         out.off_lists = o_ord + (uint32_t)(n_sched * 8 + 16);
         b.st.bytes = out.blob.size();
         out.stats = b.st;
+        out.has_long_lists = b.any_long;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
     return qr_program_verify(out, err);

@@ -43,6 +43,7 @@ struct qr_device_scene
     unsigned long long *d_counters = nullptr;
     size_t n_cells = 0;
     int32_t n_groups = 0;
+    bool divk = false;          /* some list is a long hierarchy: launch the kernel instance with the per-lane walk */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* the whole-frame wave schedule (host copy) and the schedules of the row selections rendered so far:
      * a launch restricted by qr_scene_set_rows / _set_tile_rows only starts the waves that own pixels */
@@ -189,6 +190,10 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->lp.stats = s->d_counters + 4;
     s->fr = frm;
     s->n_cells = n_cells;
+    {
+        const char *dv = getenv("QR_DIV");          /* QR_DIV=0 / 1 forces the kernel instance (experiments, tests) */
+        s->divk = dv ? atoi(dv) != 0 : prog.has_long_lists;
+    }
     s->lp.depth = frm.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : frm.depth;
     s->lp.row_begin = 0; s->lp.row_end = frm.frm_h;
     s->lp.index = frm.index; s->lp.thnum = frm.thnum > 0 ? frm.thnum : 1;
@@ -315,12 +320,13 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
     static const int waves = []() { const char *e = getenv("QR_WAVES"); int w = e ? atoi(e) : QR_MIN_WAVES_PER_SIMD;
                                     return (w == 3 || w == 4 || w == 5) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
-    if (COUNT || waves == 4) hipLaunchKernelGGL((qr_render_kernel<COUNT, 4>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
+    (void)waves;
+    if (s->divk) hipLaunchKernelGGL((qr_render_kernel<COUNT, 4, true>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
 #ifdef QR_WAVE_VARIANTS
-    else if (waves == 3) hipLaunchKernelGGL((qr_render_kernel<false, 3>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
-    else if (waves == 5) hipLaunchKernelGGL((qr_render_kernel<false, 5>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
+    else if (!COUNT && waves == 3) hipLaunchKernelGGL((qr_render_kernel<false, 3, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
+    else if (!COUNT && waves == 5) hipLaunchKernelGGL((qr_render_kernel<false, 5, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
 #endif
-    else hipLaunchKernelGGL((qr_render_kernel<false, 4>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
+    else hipLaunchKernelGGL((qr_render_kernel<COUNT, 4, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
     return hipGetLastError();
 }
 
@@ -432,8 +438,12 @@ extern "C" int qr_render_multi_async(int n, qr_device_scene *const *scenes, void
         tg.t[i].depth = scenes[i]->lp.depth;
     }
     const dim3 grid((unsigned)((ms.n + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64)), 1, 1);
-    hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD>), grid, dim3(QR_BLOCK), 0, st,
-                       tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
+    bool divk = false;
+    for (int i = 0; i < n; i++) divk = divk || scenes[i]->divk;
+    if (divk) hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD, true>), grid, dim3(QR_BLOCK), 0, st,
+                                 tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
+    else      hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD, false>), grid, dim3(QR_BLOCK), 0, st,
+                                 tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
     HIP_TRY(hipGetLastError());
     return QR_OK;
 }
@@ -782,8 +792,14 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         lp.n_blocks = (int32_t)(e1 - e0);
         lp.row_begin = (int32_t)c.prog.block_row[k]; lp.row_end = (int32_t)c.prog.block_row[k + 1];
         if (lp.n_blocks > 0)
-            hipLaunchKernelGGL((qr_render_kernel<false, 4>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
-                               lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
+        {
+            if (c.prog.has_long_lists)
+                hipLaunchKernelGGL((qr_render_kernel<false, 4, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                                   lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
+            else
+                hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                                   lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
+        }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(c.ev_k[k], c.sk);
         /* copy block k back as soon as it is rendered, on the copy stream */

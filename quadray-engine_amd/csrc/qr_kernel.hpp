@@ -185,7 +185,7 @@ struct Hit
 __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 
 /* one wave = one schedule entry: footprint `ord`, its tile-list program, rendered into `frame` */
-template <bool COUNT>
+template <bool COUNT, bool DIVK>
 __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, const u32 sched_head, const int gw,
                                             uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                                             unsigned long long *__restrict__ counters)
@@ -306,7 +306,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             Hit h; bool occ;
             /* coherent: every ray of this round is a primary ray (neighbouring pixels) */
             const bool coherent = !any_lane(tr && sp != 0);
-            traverse<false>(B, tr, coherent, ray, h, occ
+            traverse<false, DIVK>(B, tr, coherent, ray, h, occ
 #ifdef QR_STATS
                             , cx.stats
 #endif
@@ -321,7 +321,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (got && sp == 0) hit_id = (hsi << 1) | h.side;
 
             Shaded o;
-            shade<COUNT>(cx, got, coherent, ray, h, o, cnt);
+            shade<COUNT, DIVK>(cx, got, coherent, ray, h, o, cnt);
 
             if (got)
             {
@@ -479,7 +479,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 }
 
 /* single-scene launch */
-template <bool COUNT, int WAVES>
+template <bool COUNT, int WAVES, bool DIVK>
 __global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_kernel(LaunchP lp, uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
                       unsigned long long *__restrict__ counters)
@@ -491,7 +491,7 @@ void qr_render_kernel(LaunchP lp, uint32_t *__restrict__ frame, int32_t *__restr
 #pragma clang diagnostic ignored "-Wold-style-cast"
     const u32x2 sched = ((const QR_CONST u32x2 *)lp.order)[gw];
 #pragma clang diagnostic pop
-    render_wave<COUNT>(lp, sched.x, sched.y, gw, frame, ids, counters);
+    render_wave<COUNT, DIVK>(lp, sched.x, sched.y, gw, frame, ids, counters);
 }
 
 /*
@@ -506,7 +506,7 @@ void qr_render_kernel(LaunchP lp, uint32_t *__restrict__ frame, int32_t *__restr
 struct DevTarget { uint32_t *frame; const char *B; int32_t row_begin, row_end; int32_t depth, pad; };
 struct DevTargets { DevTarget t[QR_MAX_TARGETS]; };
 
-template <int WAVES>
+template <int WAVES, bool DIVK>
 __global__ __launch_bounds__(QR_BLOCK, WAVES)
 void qr_render_multi_kernel(DevTargets tg, const uint32_t *__restrict__ order16, int n_blocks,
                             unsigned long long *__restrict__ counters)
@@ -524,7 +524,7 @@ void qr_render_multi_kernel(DevTargets tg, const uint32_t *__restrict__ order16,
     lp.index = 0; lp.thnum = 1;
     lp.group_first = t.row_begin / 8; lp.group_stride = 1;
     lp.stats = nullptr; lp.dbg = 0;
-    render_wave<false>(lp, sched.x, sched.y, gw, t.frame, nullptr, counters);
+    render_wave<false, DIVK>(lp, sched.x, sched.y, gw, t.frame, nullptr, counters);
 }
 
 #endif /* QR_KERNEL_HPP */

@@ -38,7 +38,7 @@ struct Counters { u32 primary, shadow, reflect, refract; };
 /* state of the enclosing recursion that only has to survive a shade() call */
 struct Outer { V3 ret; int hit_id, sp, mode; };
 
-template <bool COUNT>
+template <bool COUNT, bool DIVK>
 __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, const Ray &r, const Hit &h,
                                       Shaded &o, Counters &cnt)
 {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         if (QR_KNOB(2)) lm = false;
         if (QR_KNOB(1)) occ = false; else
         {
-            traverse<true>(B, lm, coherent, sr, sh, occ
+            traverse<true, DIVK>(B, lm, coherent, sr, sh, occ
 #ifdef QR_STATS
                                   , cx.stats
 #endif

@@ -591,16 +591,48 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
     for (;;)
     {
-        pos = __builtin_amdgcn_readfirstlane(pos);      /* wave-uniform by construction; says so to the compiler */
-        const u32x8 c = *(const QR_CONST u32x8 *)(B + pos);
+        /*
+         * Wave-level cull (ours, not in the reference): a solver cell carries a conservative world-space bounding
+         * sphere of the surface's visible part; if every ray that is on provably misses it (perpendicular distance /
+         * behind the origin, or beyond the current depth bound) the element cannot produce a hit and is skipped
+         * without touching its record.  Never applied to a ray's own surface.  Not reference arithmetic: fused
+         * operations are fine here.  With the origin outside the sphere (|oc|^2 > 1.01 R^2) the line misses it iff
+         * b < 0 or b^2 < dd (|oc|^2 - R^2); both in one compare with b |b|; 1e-5 |oc|^2 dd on the left absorbs the
+         * rounding of both sides (a few 1e-7 relative to |oc|^2 dd), on top of the inflated radius.
+         * Runs of culled cells stay in this small loop (half of all cells of the demo scenes end here); it holds
+         * the walk's only cell load.
+         */
+        u32x8 c;
+        for (;;)
+        {
+            pos = __builtin_amdgcn_readfirstlane(pos);      /* wave-uniform by construction; says so to the compiler */
+            c = *(const QR_CONST u32x8 *)(B + pos);
+            if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
+            const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
+            const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
+            const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+            const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+            const float q = oc2 - R2;
+            const lm_t miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
+                            | LM(__builtin_fmaf(-R, dlen, b) > w.tbd);
+            const lm_t need = LM(w.resume <= pos) & ~(miss & LM(c.s1 != r.osrf));
+#ifdef QR_STATS
+            st_iter++; st_lanes += __popcll(LM(w.resume <= pos));
+#endif
+            if (need != 0) break;
+#ifdef QR_STATS
+            st_skip++;
+#endif
+            pos += 32;
+        }
         const u32 op = c.s0;
         if (op == 0) break;
         const u32 srf_off = c.s1;
         const lm_t on = LM(w.resume <= pos);
-        u32 next = pos + ((op & QR_OPT_BV) ? 64u : 32u);        /* a bounding-volume cell carries an extension slot */
+        u32 next = pos + 32;
         bool full = true;
 #ifdef QR_STATS
-        st_iter++; st_lanes += __popcll(on);
+        if (!((op & (QR_OPF_CULL | QR_OPT_BV)) == QR_OPF_CULL)) { st_iter++; st_lanes += __popcll(on); }
 #endif
         lm_t far = 0;                           /* bounding volume: lanes for which the whole array is out of reach */
         if ((op & (QR_OPF_CULL | QR_OPT_BV)) == (QR_OPF_CULL | QR_OPT_BV))
@@ -613,31 +645,6 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             far = on & (LM(__builtin_fmaf(R, dlen, b) < 0.0f) | LM(__builtin_fmaf(-R, dlen, b) > w.tbd));
             if (far != 0) { if (lane_of(far)) w.resume = c.s2; }
             full = (on & ~far) != 0;
-        }
-        else if (op & QR_OPF_CULL)
-        {
-            /*
-             * Wave-level cull (ours, not in the reference): the cell carries a conservative world-space
-             * bounding sphere of the surface's visible part; if every ray that is on provably misses it
-             * (perpendicular distance / behind the origin, or beyond the current depth bound) the element
-             * cannot produce a hit and is skipped without touching its record.  Never applied to a ray's
-             * own surface.  Not reference arithmetic: fused operations are fine here.  With the origin
-             * outside the sphere (|oc|^2 > 1.01 R^2) the line misses it iff b < 0 or b^2 < dd (|oc|^2 - R^2);
-             * both in one compare with b |b|; 1e-5 |oc|^2 dd on the left absorbs the rounding of both sides
-             * (a few 1e-7 relative to |oc|^2 dd), on top of the inflated radius.
-             */
-            const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
-            const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
-            const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
-            const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-            const float q = oc2 - R2;
-            const lm_t miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
-                            | LM(__builtin_fmaf(-R, dlen, b) > w.tbd);
-            const lm_t need = on & ~(miss & LM(srf_off != r.osrf));
-            full = need != 0;
-#ifdef QR_STATS
-            if (!full) st_skip++;
-#endif
         }
 
         if (full)
@@ -657,6 +664,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             else if (op & QR_OPT_BV)
             {
                 /* AR_ptr 3955-4054; the volume travels with the cell (CBvExt) */
+                next = pos + 64;
                 const u32x8 x = *(const QR_CONST u32x8 *)(B + pos + 32);
                 if (lane_of(on & ~far))
                 {
@@ -680,7 +688,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
                 }
             }
         }
-        if (!full && far != 0) { if (LM(w.resume <= pos) == 0) next = c.s2; }      /* nobody enters the array */
+        if (!full) next = c.s2;                 /* every ray that was on is out of the array's reach: nobody enters it */
         pos = next;
     }
     if (SHADOW) occluded = w.resume == 0xFFFFFFFFu;
@@ -853,8 +861,10 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
  * part ways (QR_LISTF_LONG) and the caller does not vouch for the rays' coherence (`coherent`: primary rays and
  * the shadow rays of primary hits -- neighbouring pixels, same light), the remaining lanes whose lists allow it
  * walk per lane.  The low bits of a list offset carry these flags (cells are 32-byte aligned).
+ * DIVK = false is the kernel instance for scenes without long hierarchies (every scene the reference engine
+ * prepares): the per-lane walk is compiled out there, which is worth 4 % of instructions through register pressure.
  */
-template <bool SHADOW>
+template <bool SHADOW, bool DIVK>
 __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS
                                          , unsigned long long *stats
@@ -869,7 +879,8 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         const int leader = __ffsll((long long)pending) - 1;
         const u32 head = (u32)__builtin_amdgcn_readlane((int)r.list, leader);
         const lm_t mine = pending & LM(r.list == head);
-#ifndef QR_NO_DIV
+        if constexpr (DIVK)
+        {
         const int n_left = __popcll(pending), n_mine = __popcll(mine);
         const lm_t can_div = pending & LM((r.list & QR_LISTF_DIV) != 0);
         const bool incoherent = n_mine * 3 <= n_left && n_left >= 12;
@@ -885,7 +896,7 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
                              );
             continue;
         }
-#endif
+        }
         pending &= ~mine;
         if (lane_of(mine))
         {

@@ -199,11 +199,14 @@ def test_gpu_tile_binning_keeps_frames(qr, name):
 VARIANT_CASES = ["demo01_160", "demo02_160_gf_aa4", "demo03_160_aa2_t2500", "test13_160", "test16_160_noopt"]
 
 
-@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "2"}, {"QR_REBIN": "1"}, {"QR_REBIN": "1", "QR_BIN_TILE": "8x8"}])
+@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "2"}, {"QR_REBIN": "1"}, {"QR_REBIN": "1", "QR_BIN_TILE": "8x8"},
+                                 {"QR_DIV": "1"}, {"QR_DIV": "1", "QR_CULL": "0"}])
 @pytest.mark.parametrize("name", VARIANT_CASES)
 def test_gpu_build_variants_match_reference(qr, name, env):
     """The knobs that change what the upload pass builds (cull cells off / on open shapes only, tile lists from
-    the binning pass at two tile sizes) leave the reference's pixels, hit ids and ray counts untouched."""
+    the binning pass at two tile sizes) and the kernel instance with the per-lane walk (QR_DIV=1: the reference's
+    scenes have no long hierarchies and get the instance without it by default) leave the reference's pixels,
+    hit ids and ray counts untouched."""
     import os
     import torch
     blob = load_blob(name)
