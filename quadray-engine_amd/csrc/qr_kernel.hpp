@@ -286,7 +286,16 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         }
     }
 
-    Frame stk[QR_MAX_DEPTH];
+    /* recursion frames: levels 0..QR_LDS_LEVELS-1 in LDS ([level][quarter][lane]: a quarter of all lanes is contiguous,
+     * 16-byte accesses at a 16-byte lane stride), deeper levels in scratch */
+    __shared__ f32x4 lds_frames[QR_LDS_LEVELS][4][64];
+    f32x4 deep[QR_MAX_DEPTH - QR_LDS_LEVELS][4];
+    auto frame_put = [&](int level, int quarter, f32x4 v) {
+        if (level < QR_LDS_LEVELS) lds_frames[level][quarter][lane] = v; else deep[level - QR_LDS_LEVELS][quarter] = v;
+    };
+    auto frame_get = [&](int level, int quarter) -> f32x4 {
+        return level < QR_LDS_LEVELS ? lds_frames[level][quarter][lane] : deep[level - QR_LDS_LEVELS][quarter];
+    };
     Outer ou;
     ou.sp = 0;
     ou.mode = inside ? 0 : 2;                   /* 0 trace, 1 return, 2 done */
@@ -329,13 +338,14 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                 const int meta = (hsi << 4) | (h.side << 3) | (o.want_rf ? 4 : 0);
                 if (o.want_tr && can_spawn)
                 {
-                    Frame &f = stk[sp];
-                    f.col[0] = o.col.x; f.col[1] = o.col.y; f.col[2] = o.col.z;
-                    f.c_trn = o.c_trn; f.c_rfl = o.c_rfl; f.x0 = o.x0;
-                    f.rdir[0] = o.rdir.x; f.rdir[1] = o.rdir.y; f.rdir[2] = o.rdir.z;
-                    f.hit[0] = o.hit.x; f.hit[1] = o.hit.y; f.hit[2] = o.hit.z;
-                    f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
-                    f.meta = meta | 1;
+                    frame_put(sp, 0, f32x4{o.col.x, o.col.y, o.col.z, __int_as_float(meta | 1)});
+                    frame_put(sp, 1, f32x4{o.c_trn, o.c_rfl, o.x0, o.hit.x});
+                    if (o.want_rf)
+                    {
+                        /* only a node that also has a reflection child needs its direction and local hit later */
+                        frame_put(sp, 2, f32x4{o.rdir.x, o.rdir.y, o.rdir.z, o.hit.y});
+                        frame_put(sp, 3, f32x4{o.loc.x, o.loc.y, o.loc.z, o.hit.z});
+                    }
                     sp++;
                     ray.org = o.hit; ray.dir = o.tdir; ray.tmin = 0.0f; ray.tmax = t_inf;
                     ray.list = o.lst_tr; ray.osrf = h.srf; ray.oflg = h.side | FLAG_PASS_THRU;
@@ -352,14 +362,10 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                     c.z = 0.0f + o.col.z * o.x0;
                     if (o.want_rf && can_spawn)
                     {
-                        Frame &f = stk[sp];
-                        f.col[0] = c.x; f.col[1] = c.y; f.col[2] = c.z;
-                        f.c_trn = o.c_trn; f.c_rfl = o.c_rfl; f.x0 = o.x0;
-                        f.rdir[0] = o.rdir.x; f.rdir[1] = o.rdir.y; f.rdir[2] = o.rdir.z;
-                        f.hit[0] = o.hit.x; f.hit[1] = o.hit.y; f.hit[2] = o.hit.z;
-                        f.loc[0] = o.loc.x; f.loc[1] = o.loc.y; f.loc[2] = o.loc.z;
-                        f.meta = meta | 2;
-                            sp++;
+                        /* a reflection-only frame is read back for its colour and factor alone */
+                        frame_put(sp, 0, f32x4{c.x, c.y, c.z, __int_as_float(meta | 2)});
+                        frame_put(sp, 1, f32x4{o.c_trn, o.c_rfl, o.x0, o.hit.x});
+                        sp++;
                         ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = t_inf;
                         ray.list = o.lst_rf; ray.osrf = h.srf; ray.oflg = h.side;
                         ray.ploc = o.loc;
@@ -384,28 +390,29 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             }
             else
             {
-                Frame &f = stk[sp - 1];
-                const int phase = f.meta & 3;
+                const f32x4 q0 = frame_get(sp - 1, 0), q1 = frame_get(sp - 1, 1);
+                const int fmeta = __float_as_int(q0.w);
+                const int phase = fmeta & 3;
                 if (phase == 1)
                 {
                     /* TR_ret + TR_mix 3534-3598 */
                     V3 c;
-                    c.x = ret.x * f.c_trn + f.col[0] * f.x0;
-                    c.y = ret.y * f.c_trn + f.col[1] * f.x0;
-                    c.z = ret.z * f.c_trn + f.col[2] * f.x0;
-                    if (f.meta & 4)
+                    c.x = ret.x * q1.x + q0.x * q1.z;
+                    c.y = ret.y * q1.x + q0.y * q1.z;
+                    c.z = ret.z * q1.x + q0.z * q1.z;
+                    if (fmeta & 4)
                     {
                         /* reflection child of the same node (depth budget is
                          * the same as for the refraction child) */
-                        f.col[0] = c.x; f.col[1] = c.y; f.col[2] = c.z;
-                        f.meta = (f.meta & ~3) | 2;
-                        const int psi = f.meta >> 4, pside = (f.meta >> 3) & 1;
-                        ray.org = {f.hit[0], f.hit[1], f.hit[2]};
-                        ray.dir = {f.rdir[0], f.rdir[1], f.rdir[2]};
+                        const f32x4 q2 = frame_get(sp - 1, 2), q3 = frame_get(sp - 1, 3);
+                        frame_put(sp - 1, 0, f32x4{c.x, c.y, c.z, __int_as_float((fmeta & ~3) | 2)});
+                        const int psi = fmeta >> 4, pside = (fmeta >> 3) & 1;
+                        ray.org = {q1.w, q2.w, q3.w};
+                        ray.dir = {q2.x, q2.y, q2.z};
                         ray.tmin = 0.0f; ray.tmax = t_inf;
                         ray.list = ((const DShade *)(cx.G + (cx.off_shade + (u32)psi * (u32)sizeof(DShade))))->lst[pside];
                         ray.osrf = QR_OFF_SRF + ((u32)psi << 7); ray.oflg = pside;
-                        ray.ploc = {f.loc[0], f.loc[1], f.loc[2]};
+                        ray.ploc = {q3.x, q3.y, q3.z};
                         mode = 0;
                         if (COUNT) cnt.reflect++;
                     }
@@ -418,9 +425,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                 else
                 {
                     /* RF_ret + RF_mix 3868-3908 */
-                    ret.x = ret.x * f.c_rfl + f.col[0];
-                    ret.y = ret.y * f.c_rfl + f.col[1];
-                    ret.z = ret.z * f.c_rfl + f.col[2];
+                    ret.x = ret.x * q1.y + q0.x;
+                    ret.y = ret.y * q1.y + q0.y;
+                    ret.z = ret.z * q1.y + q0.z;
                     sp--;
                 }
             }

@@ -10,15 +10,21 @@
 /* shading of the final hit, tracer.cpp:2166-3930 without the child packets  */
 /* ------------------------------------------------------------------------ */
 
+/*
+ * One level of a ray's recursion (the reference's context stack, tracer.h:426-665), 16 dwords in four 16-byte
+ * quarters.  The two shallowest levels of every lane live in LDS -- a one-wave workgroup has 10 KB of it to itself at
+ * 16 waves per CU, and most recursion ends at depth 1-2 -- the deeper ones in scratch.  A return reads q0 and q1;
+ * q2 and q3 are only read when a node with a refraction child also has a reflection child to start.
+ */
 struct Frame
 {
-    float col[3];
-    float c_trn, c_rfl, x0;
-    float rdir[3];
-    float hit[3];
-    float loc[3];
-    int   meta;             /* si << 4 | side << 3 | rf << 2 | phase (1 TR, 2 RF) */
+    float col[3]; int meta;             /* q0: colour so far; si << 4 | side << 3 | rf << 2 | phase (1 TR, 2 RF) */
+    float c_trn, c_rfl, x0, hit0;       /* q1 */
+    float rdir[3]; float hit1;          /* q2: the reflection child's direction */
+    float loc[3]; float hit2;           /* q3: the local hit (the child's ploc) */
 };
+#define QR_LDS_LEVELS 2
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Shaded
 {
