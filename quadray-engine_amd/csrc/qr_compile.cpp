@@ -305,6 +305,9 @@ struct Builder
                 arr_sphere[i].c[0] = c0.c[0]; arr_sphere[i].c[1] = c0.c[1]; arr_sphere[i].c[2] = c0.c[2]; arr_sphere[i].r = (float)R * 1.0001f;
                 ch[i].op |= QR_OPF_CULL;
             }
+        bool has_trnode = false;
+        for (int i = 0; i < n; i++)
+            if (ch[i].emit && ((ch[i].op & QR_OPT_TRNODE) || (ch[i].op & QR_OPF_CACHED))) has_trnode = true;
         /* emit */
         emit_idx.assign((size_t)n + 1, 0);
         int ne = 0;
@@ -338,6 +341,20 @@ struct Builder
                 memset(&x, 0, sizeof(x));
                 for (int k = 0; k < 3; k++) x.pos[k] = q.pos[k];
                 for (int k = 0; k < 4; k++) x.sci[k] = q.sci[k];
+                /* hand-over boundary: the child (direct member or nested array) that starts nearest to the middle of the
+                 * array's cells.  Only where a walk carries no trnode state and the array is worth splitting. */
+                const int s0 = emit_idx[i] + 2, s1 = emit_idx[ch[i].last + 1];
+                if (!has_trnode && s1 - s0 >= 12)
+                {
+                    int best = -1;
+                    for (int k = i + 1; k <= ch[i].last; )
+                    {
+                        if (ch[k].emit && emit_idx[k] > s0 && (best < 0 || abs(2 * emit_idx[k] - (s0 + s1)) < abs(2 * emit_idx[best] - (s0 + s1))))
+                            best = k;
+                        k = (ch[k].emit && (ch[k].op & QR_OPT_BV)) ? ch[k].last + 1 : k + 1;
+                    }
+                    if (best >= 0) x.mid = off + (uint32_t)emit_idx[best] * (uint32_t)sizeof(CCell);
+                }
                 *at<CBvExt>(off + (uint32_t)(emit_idx[i] + 1) * (uint32_t)sizeof(CCell)) = x;
             }
         }
@@ -686,6 +703,11 @@ int qr_program_verify(const QrProgram &p, std::string &err)
             if (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf)) return "cell surface offset out of range";
             if (t == QR_OPT_BV && (c->end <= o + 32 || c->end > end_cell || (c->end & 31) || !(slot[c->end / 32] & 2)))
                 return "array end outside its list";
+            if (t == QR_OPT_BV)
+            {
+                const uint32_t mid = ((const CBvExt *)(b.data() + o + 32))->mid;
+                if (mid != 0 && (mid <= o + 64 || mid >= c->end || (mid & 31) || !(slot[mid / 32] & 2))) return "array hand-over boundary outside the array";
+            }
             if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
             if ((c->op & QR_OPF_CULL) && !(t & (QR_OPT_SOLVER | QR_OPT_BV))) return "cull flag on a cell without solver or volume";
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";

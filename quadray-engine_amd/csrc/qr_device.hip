@@ -321,7 +321,7 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
                                     return (w == 3 || w == 4 || w == 5) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
     (void)waves;
-    if (s->divk) hipLaunchKernelGGL((qr_render_kernel<COUNT, 4, true>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
+    if (s->divk) hipLaunchKernelGGL((qr_render_kernel<COUNT, QR_DIVK_WAVES, true>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
 #ifdef QR_WAVE_VARIANTS
     else if (!COUNT && waves == 3) hipLaunchKernelGGL((qr_render_kernel<false, 3, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
     else if (!COUNT && waves == 5) hipLaunchKernelGGL((qr_render_kernel<false, 5, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
@@ -440,7 +440,7 @@ extern "C" int qr_render_multi_async(int n, qr_device_scene *const *scenes, void
     const dim3 grid((unsigned)((ms.n + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64)), 1, 1);
     bool divk = false;
     for (int i = 0; i < n; i++) divk = divk || scenes[i]->divk;
-    if (divk) hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD, true>), grid, dim3(QR_BLOCK), 0, st,
+    if (divk) hipLaunchKernelGGL((qr_render_multi_kernel<QR_DIVK_WAVES, true>), grid, dim3(QR_BLOCK), 0, st,
                                  tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
     else      hipLaunchKernelGGL((qr_render_multi_kernel<QR_MIN_WAVES_PER_SIMD, false>), grid, dim3(QR_BLOCK), 0, st,
                                  tg, (const uint32_t *)ms.d_order, ms.n, scenes[0]->d_counters);
@@ -474,6 +474,10 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
         fprintf(stderr, "QR_STATS per-lane walks %llu: steps %llu (%.1f per walk, %.1f lanes stepping), solve rounds %llu (%.1f lanes solving)\n",
                 st[16], st[17], st[16] ? (double)st[17] / st[16] : 0.0, st[17] ? (double)st[18] / st[17] : 0.0,
                 st[19], st[19] ? (double)st[20] / st[19] : 0.0);
+        fprintf(stderr, "QR_STATS per-lane SHADOW walks %llu: steps %llu (%.1f per walk, %.1f lanes stepping, %.1f lanes at start), solve rounds %llu; non-shadow lanes at start %.1f\n",
+                st[9], st[10], st[9] ? (double)st[10] / st[9] : 0.0, st[10] ? (double)st[11] / st[10] : 0.0,
+                st[9] ? (double)st[15] / st[9] : 0.0, st[22], st[16] ? (double)st[21] / st[16] : 0.0);
+        fprintf(stderr, "QR_STATS ranges handed over %llu\n", st[23]);
         const char *nm[3] = { "shadow", "primary", "secondary" };
         for (int k = 0; k < 3; k++)
             fprintf(stderr, "QR_STATS %s: walks %llu elem-iterations %llu (%.1f per walk, %.0f%% culled) active lanes per iteration %.1f\n", nm[k],
@@ -794,7 +798,7 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         if (lp.n_blocks > 0)
         {
             if (c.prog.has_long_lists)
-                hipLaunchKernelGGL((qr_render_kernel<false, 4, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
             else
                 hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,

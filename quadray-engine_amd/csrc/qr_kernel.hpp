@@ -67,6 +67,9 @@
 #ifndef QR_MIN_WAVES_PER_SIMD
 #define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
 #endif
+#ifndef QR_DIVK_WAVES
+#define QR_DIVK_WAVES 4           /* the instance with the per-lane walks: 128 VGPRs and ~70 spilled beat 168 and none (latency: -8 % frame time) */
+#endif
 
 typedef uint32_t u32;
 #define QR_SMASK 0x80000000u
@@ -286,15 +289,16 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         }
     }
 
-    /* recursion frames: levels 0..QR_LDS_LEVELS-1 in LDS ([level][quarter][lane]: a quarter of all lanes is contiguous,
+    /* recursion frames: levels 0..LDSL-1 in LDS ([level][quarter][lane]: a quarter of all lanes is contiguous,
      * 16-byte accesses at a 16-byte lane stride), deeper levels in scratch */
-    __shared__ f32x4 lds_frames[QR_LDS_LEVELS][4][64];
-    f32x4 deep[QR_MAX_DEPTH - QR_LDS_LEVELS][4];
+    constexpr int LDSL = DIVK ? QR_LDS_LEVELS_DIVK : QR_LDS_LEVELS;
+    __shared__ f32x4 lds_frames[LDSL][4][64];
+    f32x4 deep[QR_MAX_DEPTH - LDSL][4];
     auto frame_put = [&](int level, int quarter, f32x4 v) {
-        if (level < QR_LDS_LEVELS) lds_frames[level][quarter][lane] = v; else deep[level - QR_LDS_LEVELS][quarter] = v;
+        if (level < LDSL) lds_frames[level][quarter][lane] = v; else deep[level - LDSL][quarter] = v;
     };
     auto frame_get = [&](int level, int quarter) -> f32x4 {
-        return level < QR_LDS_LEVELS ? lds_frames[level][quarter][lane] : deep[level - QR_LDS_LEVELS][quarter];
+        return level < LDSL ? lds_frames[level][quarter][lane] : deep[level - LDSL][quarter];
     };
     Outer ou;
     ou.sp = 0;

@@ -35,7 +35,14 @@ struct CCell                    /* 32 B, 32-byte aligned */
 };
 
 /* second slot of a QR_OPT_BV cell: the fields of the volume's surface record that AR_ptr reads */
-struct CBvExt { float pos[3]; uint32_t pad; float sci[4]; };
+struct CBvExt
+{
+    float pos[3];
+    uint32_t mid;               /* byte offset of a later child of the array, near the middle of its cells: from there on the
+                                 * rest of a walk can be handed to another lane (walk_pool); 0 = none (small array, or the
+                                 * list carries trnode state)                                                            */
+    float sci[4];
+};
 
 /* cell type: one bit each, so that the walk tests them with s_bitcmp in the order of their frequency
  * (a dense enum makes the compiler build a compare tree) */

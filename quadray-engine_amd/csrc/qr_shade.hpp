@@ -24,6 +24,9 @@ struct Frame
     float loc[3]; float hit2;           /* q3: the local hit (the child's ploc) */
 };
 #define QR_LDS_LEVELS 2
+#ifndef QR_LDS_LEVELS_DIVK
+#define QR_LDS_LEVELS_DIVK 1    /* the instance with walk_pool keeps 2.5 KB of LDS for it: 16 waves per CU need <= 10 KB each */
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Shaded

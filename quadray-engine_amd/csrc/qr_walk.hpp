@@ -731,7 +731,7 @@ __device__ __forceinline__ bool div_culled(const u32x4 &c0, const u32x4 &c1, con
 }
 
 #ifndef QR_DIV_BATCH
-#define QR_DIV_BATCH 24     /* per-lane walk: solve as soon as this many lanes hold a candidate cell */
+#define QR_DIV_BATCH 16     /* per-lane walk: solve as soon as this many lanes hold a candidate cell (24: +3 %, 32: +6 % frame time) */
 #endif
 
 /*
@@ -846,10 +846,269 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
     }
     if (SHADOW) { if (w.resume == 0xFFFFFFFFu) occluded = true; }   /* only the lanes that walked here */
 #ifdef QR_STATS
+    const unsigned long long st_start = (unsigned long long)__popcll(__ballot(active));
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
     {
-        atomicAdd(&stats[16], 1ull); atomicAdd(&stats[17], st_iter); atomicAdd(&stats[18], st_lanes);
-        atomicAdd(&stats[19], st_solve); atomicAdd(&stats[20], st_slanes);
+        if (SHADOW) { atomicAdd(&stats[9], 1ull); atomicAdd(&stats[10], st_iter); atomicAdd(&stats[11], st_lanes);
+                      atomicAdd(&stats[15], st_start); atomicAdd(&stats[22], st_solve); }
+        else        { atomicAdd(&stats[16], 1ull); atomicAdd(&stats[17], st_iter); atomicAdd(&stats[18], st_lanes);
+                      atomicAdd(&stats[19], st_solve); atomicAdd(&stats[20], st_slanes);
+                      atomicAdd(&stats[21], st_start); }
+    }
+#endif
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* walk_pool: the per-lane walk with WORK HAND-OVER between the lanes of the wave.                              */
+/* ------------------------------------------------------------------------------------------------------------ */
+#ifndef QR_INCOH_MIN
+#define QR_INCOH_MIN 3      /* lanes left when the leader's group is at most a third of them: walk per lane (measured 3 vs 12: -7 % frame time) */
+#endif
+#ifndef QR_POOL
+#define QR_POOL 1          /* 0: walk_div without hand-over (A/B) */
+#endif
+#ifndef QR_POOL_MIN_IDLE
+#define QR_POOL_MIN_IDLE 12     /* hand-over round as soon as this many lanes have nothing to do (2: +2 %, 6: +1.5 % frame time) */
+#endif
+#ifndef QR_POOL_MIN_BYTES
+#define QR_POOL_MIN_BYTES 384u  /* a lane only gives a range of at least this many bytes of cells away */
+#endif
+
+/* LDS of the one-wave workgroup used by walk_pool (one object for both instantiations) */
+struct PoolLds
+{
+    unsigned long long key[64];     /* per ray (= owner lane).  Nearest hit: (t bits << 32) | offset of the hit's cell, the
+                                     * minimum over everything walked for that ray so far; shadow: != 0 once occluded      */
+    u32x4 hit[64];                  /* payload of the hit `key` stands for: {srf | side, loc}                              */
+    u32x4 give[64];                 /* hand-over slots: {owner, first cell, end of range, -}                               */
+};
+__device__ __forceinline__ PoolLds &pool_lds() { __shared__ PoolLds p; return p; }
+
+__device__ __forceinline__ int lanes_below(lm_t m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+/*
+ * walk_div leaves most of the wave idle on a long hierarchy: rays end at very different times (a shadow ray is
+ * occluded after 5 cells or walks 400), measured 6.9 (shadow) / 15.7 (secondary) of 64 lanes stepping on the 10 000
+ * object scene.  Here a lane's work is a RANGE of its ray's list program [pos, iend), and a lane that has entered a
+ * bounding volume knows a cell boundary ahead of it (`give`: the start of a later child of that volume, stored by
+ * the compiler in the volume's cell, CBvExt::mid) from which on the rest of its range can be walked by somebody
+ * else: every enclosing volume has been entered, the list has no trnode state (the compiler only stores boundaries
+ * where that holds), so the cells from there on mean the same to any lane that holds the ray.  As soon as
+ * QR_POOL_MIN_IDLE lanes are idle, lanes with such a boundary hand [give, iend) to them (slots in LDS, the ray itself
+ * through ds_bpermute from its owner's registers) and keep [pos, give).
+ * Results meet in LDS per ray: a shadow ray's occlusion flag (everybody on that ray stops), or the minimum of
+ * (t, cell offset) over the hits of all ranges of that ray -- the reference takes the first cell in list order among
+ * equal depths (strict compare, tracer.cpp:1626), which is exactly that minimum, so the order in which ranges are
+ * walked does not matter.  Depth tests inside a range use the range's own bound; the best depth known for the ray when
+ * the range was taken only feeds the conservative sphere culls.
+ */
+template <bool SHADOW>
+__device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hit &h, bool &occluded
+#ifdef QR_STATS
+                                          , unsigned long long *stats
+#endif
+                                          )
+{
+    PoolLds &P = pool_lds();
+    const int lane = (int)(threadIdx.x & 63u);
+    Ray cr = r;                                 /* the ray this lane walks for (its own to begin with) */
+    int owner = lane;
+    WalkState w;
+    w.txyz = {0, 0, 0}; w.trijk = {0, 0, 0};
+    w.tbuf = cr.tmax;
+    w.resume = 0;
+    float dd = cr.dir.x * cr.dir.x + cr.dir.y * cr.dir.y + cr.dir.z * cr.dir.z;
+    float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    float dde = dd * 1e-5f;
+    float cull_t = cr.tmax;                     /* best depth known for the ray when this range was taken */
+    w.tbd = w.tbuf * dd;
+    u32 pos = active ? (r.list & ~31u) : 0u;    /* 0: nothing to walk */
+    u32 iend = 0xFFFFFFFFu;                     /* end of the range; the first range of a ray ends at the END cell */
+    u32 give = 0;
+    u32 p_op = 0, p_srf = 0, p_pos = 0;         /* the candidate cell the lane stands on (p_op == 0: none) */
+    bool busy = active;
+    Hit lh; lh.t = 0.0f; lh.srf = 0; lh.side = 0; lh.loc = {0, 0, 0};
+    u32 lh_pos = 0;
+    P.key[lane] = SHADOW ? 0ull : (((unsigned long long)f2u(r.tmax) << 32) | 0xFFFFFFFFull);
+    __syncthreads();
+#ifdef QR_STATS
+    unsigned long long st_iter = 0, st_lanes = 0, st_solve = 0, st_slanes = 0, st_give = 0;
+#endif
+    for (;;)
+    {
+        const lm_t pend = LM(p_op != 0);
+        const lm_t adv = LM(pos != 0) & ~pend;
+        const lm_t work = adv | pend;
+        /* ranges that ended: their best hit meets the ray's */
+        const lm_t fin = LM(busy) & ~work;
+        if (fin != 0)
+        {
+            const bool f = lane_of(fin);
+            if (f) busy = false;
+            if (!SHADOW)
+            {
+                const bool hv = f && lh.srf != 0;
+                const unsigned long long k = ((unsigned long long)f2u(lh.t) << 32) | (unsigned long long)lh_pos;
+                if (hv) atomicMin(&P.key[owner], k);
+                __syncthreads();
+                if (hv && P.key[owner] == k)
+                    P.hit[owner] = u32x4{lh.srf | (u32)lh.side, f2u(lh.loc.x), f2u(lh.loc.y), f2u(lh.loc.z)};
+            }
+        }
+        if (work == 0) break;
+
+        /* ---- hand-over ---- */
+        const bool can_give = pos != 0 && give > pos && (iend - give) >= QR_POOL_MIN_BYTES;
+        const lm_t givers = LM(can_give);
+        const lm_t idle = ~work;
+        if (givers != 0 && __popcll(idle) >= QR_POOL_MIN_IDLE)
+        {
+            const int n_g = __popcll(givers), n_i = __popcll(idle);
+            const int rank_g = lanes_below(givers), rank_i = lanes_below(idle);
+            if (can_give && rank_g < n_i)
+            {
+                P.give[rank_g] = u32x4{(u32)owner, give, iend, 0u};
+                iend = give; give = 0;
+            }
+            __syncthreads();
+            const bool tk = lane_of(idle) && rank_i < n_g;
+            const u32x4 g = P.give[tk ? rank_i : 0];
+            const int src = tk ? (int)g.x : lane;
+            /* the ray of `src` from its owner's registers (every lane of the wave executes this) */
+            const float ox = __shfl(r.org.x, src), oy = __shfl(r.org.y, src), oz = __shfl(r.org.z, src);
+            const float dx = __shfl(r.dir.x, src), dy = __shfl(r.dir.y, src), dz = __shfl(r.dir.z, src);
+            const float tmn = __shfl(r.tmin, src), tmx = __shfl(r.tmax, src);
+            const u32 osf = (u32)__shfl((int)r.osrf, src); const int ofl = __shfl(r.oflg, src);
+            const float px = __shfl(r.ploc.x, src), py = __shfl(r.ploc.y, src), pz = __shfl(r.ploc.z, src);
+            if (tk)
+            {
+                owner = src; pos = g.y; iend = g.z; give = 0; busy = true;
+                cr.org = {ox, oy, oz}; cr.dir = {dx, dy, dz}; cr.tmin = tmn; cr.tmax = tmx;
+                cr.osrf = osf; cr.oflg = ofl; cr.ploc = {px, py, pz};
+                dd = dx * dx + dy * dy + dz * dz;
+                dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+                dde = dd * 1e-5f;
+                w.tbuf = tmx; w.resume = 0;
+                lh.srf = 0;
+                cull_t = SHADOW ? tmx : u2f((u32)(P.key[src] >> 32));
+                w.tbd = cull_t * dd;
+            }
+            __syncthreads();                    /* slots are free again */
+#ifdef QR_STATS
+            st_give += (unsigned long long)(n_g < n_i ? n_g : n_i);
+#endif
+            continue;
+        }
+
+        if (adv != 0 && __popcll(pend) < QR_DIV_BATCH)
+        {
+            /* ---- STEP (as walk_div) ---- */
+#ifdef QR_STATS
+            st_iter++; st_lanes += __popcll(adv);
+#endif
+            if (lane_of(adv))
+            {
+                const u32x4 a0 = *(const QR_CONST u32x4 *)(B + pos), a1 = *(const QR_CONST u32x4 *)(B + pos + 16),
+                            b0 = *(const QR_CONST u32x4 *)(B + pos + 32), b1 = *(const QR_CONST u32x4 *)(B + pos + 48);
+                const u32 op = a0.x, srf_off = a0.y;
+                u32 next = pos + 32;
+                bool stop = op == 0;
+                if (SHADOW) stop = stop || ((const volatile u32 *)&P.key[owner])[0] != 0u;     /* somebody found the ray occluded */
+                if (stop) next = 0;
+                else if (op & QR_OPT_SOLVER)
+                {
+                    if (!(op & QR_OPF_CULL) || !div_culled(a0, a1, cr, dd, dde, dlen, w.tbd)) { p_op = op; p_srf = srf_off; p_pos = pos; }
+                    else if ((b0.x & QR_OPT_SOLVER) != 0 && pos + 32 < iend)
+                    {
+                        next = pos + 64;
+                        if (!(b0.x & QR_OPF_CULL) || !div_culled(b0, b1, cr, dd, dde, dlen, w.tbd)) { p_op = b0.x; p_srf = b0.y; p_pos = pos + 32; }
+                    }
+                }
+                else if (op & QR_OPT_BV)
+                {
+                    next = pos + 64;
+                    bool far = false;
+                    if (op & QR_OPF_CULL)
+                    {
+                        const float R = u2f(a1.w);
+                        const float ocx = u2f(a1.x) - cr.org.x, ocy = u2f(a1.y) - cr.org.y, ocz = u2f(a1.z) - cr.org.z;
+                        const float bb = __builtin_fmaf(ocz, cr.dir.z, __builtin_fmaf(ocy, cr.dir.y, ocx * cr.dir.x));
+                        far = (__builtin_fmaf(R, dlen, bb) < 0.0f) | (__builtin_fmaf(-R, dlen, bb) > w.tbd);
+                    }
+                    if (far) next = a0.z;
+                    else
+                    {
+                        V3 df, ry;
+                        cell_space(B, op, srf_off, u2f(b0.x), u2f(b0.y), u2f(b0.z), cr, w, df, ry);
+                        if (!bv_hit(ry, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w))) next = a0.z;
+                        else if (give <= pos) give = b0.w;          /* entered: a later child of this volume starts there */
+                    }
+                }
+                else
+                {
+                    const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
+                    V3 d;
+                    d.x = cr.org.x - u2f(p0.x); d.y = cr.org.y - u2f(p0.y); d.z = cr.org.z - u2f(p0.z);
+                    w.txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
+                    w.trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, cr.dir);
+                }
+                if (next >= iend) next = 0;
+                pos = next;
+            }
+        }
+        else
+        {
+            /* ---- SOLVE ---- */
+#ifdef QR_STATS
+            st_solve++; st_slanes += __popcll(pend);
+#endif
+            if (lane_of(pend))
+            {
+                SurfS s;
+                ld_surf_lane(B, p_srf, s);
+                const float tb = w.tbuf;
+                solve_cell<SHADOW, true>(B, p_op, p_srf, s, cr, dd, w, lh);
+                p_op = 0;
+                if (SHADOW)
+                {
+                    if (w.resume == 0xFFFFFFFFu) { pos = 0; ((volatile u32 *)&P.key[owner])[0] = 1u; }
+                }
+                else if (w.tbuf != tb)
+                {
+                    lh_pos = p_pos;
+                    w.tbd = __builtin_fminf(w.tbd, cull_t * dd);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active)
+    {
+        const unsigned long long k = P.key[lane];
+        if (SHADOW) { if (k != 0ull) occluded = true; }
+        else if ((u32)k != 0xFFFFFFFFu)
+        {
+            const u32x4 q = P.hit[lane];
+            const u32 ss = q.x;
+            h.t = u2f((u32)(k >> 32)); h.srf = ss & ~1u; h.side = (int)(ss & 1u);
+            h.loc = {u2f(q.y), u2f(q.z), u2f(q.w)};
+        }
+    }
+    __syncthreads();                            /* the next walk starts by writing the slots again */
+#ifdef QR_STATS
+    const unsigned long long st_start = (unsigned long long)__popcll(__ballot(active));
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        if (SHADOW) { atomicAdd(&stats[9], 1ull); atomicAdd(&stats[10], st_iter); atomicAdd(&stats[11], st_lanes);
+                      atomicAdd(&stats[15], st_start); atomicAdd(&stats[22], st_solve); }
+        else        { atomicAdd(&stats[16], 1ull); atomicAdd(&stats[17], st_iter); atomicAdd(&stats[18], st_lanes);
+                      atomicAdd(&stats[19], st_solve); atomicAdd(&stats[20], st_slanes);
+                      atomicAdd(&stats[21], st_start); }
+        atomicAdd(&stats[23], st_give);
     }
 #endif
 }
@@ -883,17 +1142,25 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         {
         const int n_left = __popcll(pending), n_mine = __popcll(mine);
         const lm_t can_div = pending & LM((r.list & QR_LISTF_DIV) != 0);
-        const bool incoherent = n_mine * 3 <= n_left && n_left >= 12;
+        const bool incoherent = n_mine * 3 <= n_left && n_left >= QR_INCOH_MIN;
         const bool long_list = !coherent && (head & QR_LISTF_LONG) != 0 && (head & QR_LISTF_DIV) != 0 && n_mine >= 4;
         if ((incoherent || long_list) && can_div != 0)
         {
             const lm_t go = incoherent ? can_div : mine;
             pending &= ~go;
+#if QR_POOL
+            walk_pool<SHADOW>(B, lane_of(go), r, h, occluded
+#ifdef QR_STATS
+                              , stats
+#endif
+                              );
+#else
             walk_div<SHADOW>(B, lane_of(go), r, h, occluded
 #ifdef QR_STATS
                              , stats
 #endif
                              );
+#endif
             continue;
         }
         }

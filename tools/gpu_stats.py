@@ -20,3 +20,5 @@ if len(sys.argv) > 2:
 print(name, "depth", scn.info.depth, flush=True)
 _, c = scn.render_count()
 print(c.as_dict(), flush=True)
+import numpy as np
+f = scn.new_frame(); scn.render(f); torch.cuda.synchronize(); print("hash %016x" % qr.frame_hash(f), flush=True)
