@@ -304,6 +304,27 @@ struct Builder
                 if (!(R < 1e18)) continue;
                 arr_sphere[i].c[0] = c0.c[0]; arr_sphere[i].c[1] = c0.c[1]; arr_sphere[i].c[2] = c0.c[2]; arr_sphere[i].r = (float)R * 1.0001f;
                 ch[i].op |= QR_OPF_CULL;
+                /* the volume itself a plain sphere around all members' bounds?  Then it is the cull sphere. */
+                const qr_surface &q = v.srf[ch[i].si];
+                if (!(ch[i].op & QR_OPF_LOCAL) && q.has_trm == 0 && q.sci[0] == 1.0f && q.sci[1] == 1.0f && q.sci[2] == 1.0f
+                    && q.sci[3] > 0.0f && q.sci[3] < 1e30f)
+                {
+                    const double rq = __builtin_sqrt((double)q.sci[3]);
+                    bool inside = true;
+                    for (int k = i + 1; k <= ch[i].last && inside; k++)
+                        if (ch[k].emit && (ch[k].op & QR_OPT_SOLVER))
+                        {
+                            const BSphere &m = bs[ch[k].si];
+                            const double dx = (double)m.c[0] - q.pos[0], dy = (double)m.c[1] - q.pos[1], dz = (double)m.c[2] - q.pos[2];
+                            if (__builtin_sqrt(dx * dx + dy * dy + dz * dz) + (double)m.r > rq * 1.0001) inside = false;
+                        }
+                    if (inside)
+                    {
+                        arr_sphere[i].c[0] = q.pos[0]; arr_sphere[i].c[1] = q.pos[1]; arr_sphere[i].c[2] = q.pos[2];
+                        arr_sphere[i].r = (float)(rq * 1.0002 + 1e-4);
+                        ch[i].op |= QR_OPF_SPHBV;
+                    }
+                }
             }
         bool has_trnode = false;
         for (int i = 0; i < n; i++)
@@ -325,12 +346,14 @@ struct Builder
             c.op = ch[i].op; c.srf = srf_off(ch[i].si);
             if (c.op & QR_OPT_BV) c.end = off + (uint32_t)emit_idx[ch[i].last + 1] * (uint32_t)sizeof(CCell);
             c.r = __builtin_inff();
+            if (!(c.op & QR_OPT_BV)) { c.r2 = __builtin_inff(); c.r2x = __builtin_inff(); }   /* no cull: no test of walk_pool's fails */
             if (c.op & QR_OPF_CULL)
             {
                 const BSphere &bsp = (c.op & QR_OPT_BV) ? arr_sphere[i] : bs[ch[i].si];
                 c.cx = bsp.c[0]; c.cy = bsp.c[1]; c.cz = bsp.c[2]; c.r = bsp.r;
                 if (!(c.op & QR_OPT_BV)) { c.r2 = bsp.r * bsp.r; c.r2x = c.r2 * 1.01f; }      /* BV: the slot holds `end` */
             }
+            if (c.op & QR_OPT_BV) c.r2x = (c.op & QR_OPF_SPHBV) ? -1.0f : __builtin_inff();
             *at<CCell>(off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell)) = c;
             if (c.op & QR_OPT_BV)
             {
@@ -378,6 +401,10 @@ struct Builder
             if (ch[i].op & QR_OPT_BV) n_bv++;
         }
         if (n_emitted >= 96 && n_bv >= 4) { lf |= QR_LISTF_LONG; any_long = true; }
+        bool world = true;
+        for (int i = 0; i < n; i++)
+            if (ch[i].emit && ((ch[i].op & QR_OPT_TRNODE) || (ch[i].op & QR_OPF_LOCAL))) world = false;
+        if (world) lf |= QR_LISTF_WORLD;
         list_off[head] = off | lf;
         list_heavy[head] = heavy;
         return off | lf;
@@ -681,11 +708,12 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     /* a list program: cells inside the list area, END-terminated, array ends on cell boundaries inside the run */
     auto check_list = [&](uint32_t off) -> const char * {
         if (off == 0) return nullptr;
-        if (off & 28u) return "list offset carries unknown flag bits";
+        if (off & 24u) return "list offset carries unknown flag bits";
+        const bool world = (off & QR_LISTF_WORLD) != 0;
         off &= ~31u;
         if (off < p.off_lists || (size_t)off + 32 > limit) return "list offset out of range";
-        if (slot[off / 32] & 1) return nullptr;
-        slot[off / 32] |= 1;
+        if (slot[off / 32] & 1) return ((slot[off / 32] & 4) != 0) == world ? nullptr : "list referenced with different flags";
+        slot[off / 32] |= world ? 5 : 1;
         uint32_t o = off, end_cell = 0;
         for (;;)
         {
@@ -709,7 +737,9 @@ int qr_program_verify(const QrProgram &p, std::string &err)
                 if (mid != 0 && (mid <= o + 64 || mid >= c->end || (mid & 31) || !(slot[mid / 32] & 2))) return "array hand-over boundary outside the array";
             }
             if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
+            if (world && (t == QR_OPT_TRNODE || (c->op & QR_OPF_LOCAL))) return "transform in a list flagged world-space";
             if ((c->op & QR_OPF_CULL) && !(t & (QR_OPT_SOLVER | QR_OPT_BV))) return "cull flag on a cell without solver or volume";
+            if ((c->op & QR_OPF_SPHBV) && (t != QR_OPT_BV || !(c->op & QR_OPF_CULL) || (c->op & QR_OPF_LOCAL))) return "sphere-volume flag on the wrong kind of cell";
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
             if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";
             o += (t == QR_OPT_BV) ? 64 : 32;
@@ -797,6 +827,8 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
     QrProgram p;
     rc = qr_program_build(v, E, T, *v.frame, bs, p, err);
     if (rc != QR_OK) return qr_fail(rc, err);
+    if (const char *dump = getenv("QR_DUMP_IMAGE"))        /* debugging aid: the device image as a file */
+        if (FILE *f = fopen(dump, "wb")) { fwrite(p.blob.data(), 1, p.blob.size(), f); fclose(f); }
     memset(info, 0, sizeof(*info));
     info->bytes = p.stats.bytes; info->n_lists = p.stats.n_lists; info->n_cells = p.stats.n_cells;
     info->n_dropped = p.stats.n_dropped; info->n_clip_cells = p.stats.n_clip_cells; info->n_sched = p.n_sched;

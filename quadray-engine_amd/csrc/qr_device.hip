@@ -175,9 +175,9 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     const size_t n_sched = prog.n_sched;
 #ifdef QR_WAVETIME
-    e = hipMalloc((void **)&s->d_counters, (32 + QR_WT_SLOTS * n_sched) * sizeof(unsigned long long));
+    e = hipMalloc((void **)&s->d_counters, (64 + QR_WT_SLOTS * n_sched) * sizeof(unsigned long long));
 #else
-    e = hipMalloc((void **)&s->d_counters, 32 * sizeof(unsigned long long));
+    e = hipMalloc((void **)&s->d_counters, 64 * sizeof(unsigned long long));
 #endif
     if (e != hipSuccess) { (void)hipFree(s->d_blob); delete s; return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     s->blob_bytes = total;
@@ -461,7 +461,7 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     if (s == nullptr || frame_dev == nullptr || counts == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 64 * sizeof(unsigned long long), st));
     HIP_TRY(launch<true>(s, frame_dev, nullptr, st));
     unsigned long long h[4];
     HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -469,8 +469,9 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
 #ifdef QR_STATS
     {
-        unsigned long long st[24];
+        unsigned long long st[32];
         HIP_TRY(hipMemcpy(st, s->d_counters + 4, sizeof(st), hipMemcpyDeviceToHost));
+        if (st[27]) fprintf(stderr, "QR_GUARD %llu bad cell offsets; first: tag %llu offset 0x%llx context 0x%llx\n", st[27], st[24], st[25], st[26]);
         fprintf(stderr, "QR_STATS per-lane walks %llu: steps %llu (%.1f per walk, %.1f lanes stepping), solve rounds %llu (%.1f lanes solving)\n",
                 st[16], st[17], st[16] ? (double)st[17] / st[16] : 0.0, st[17] ? (double)st[18] / st[17] : 0.0,
                 st[19], st[19] ? (double)st[20] / st[19] : 0.0);

@@ -69,10 +69,14 @@ struct CBvExt
 #define QR_OPF_SIDESHAD (1u << 15)  /*   ... occludes depending on the side hit (look at the props)       */
 #define QR_OPF_CLIP    (1u << 16)   /* surface has custom clippers                                        */
 #define QR_OPF_CONIC   (1u << 17)   /* conic singularity fix applies (cones, hyper-cylinders)             */
+#define QR_OPF_SPHBV   (1u << 18)   /* bounding volume is an untransformed world-space sphere that holds all its members'
+                                     * bounds: its cull sphere is that sphere (x 1.0002), the r2x slot holds -1 (0x7F800000
+                                     * = +inf otherwise), and the per-lane walk decides most rays from the sphere alone */
 
 /* flags in the low bits of a list offset (list programs are 32-byte aligned), carried wherever a list is referenced */
 #define QR_LISTF_DIV   1u       /* no cell has a clipper program: the per-lane walk may take this list      */
 #define QR_LISTF_LONG  2u       /* a long hierarchy (bounding-volume arrays, many cells): rays part ways on it */
+#define QR_LISTF_WORLD 4u       /* every cell reads the world-space ray: no trnode cell, no QR_OPF_CACHED / QR_OPF_OWN cell */
 #define QR_LIST_OFF(x) ((x) & ~31u)
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */

@@ -22,6 +22,13 @@
  * active where they were computed.
  */
 typedef unsigned long long lm_t;
+#if defined(QR_STATS) && defined(QR_GUARD)
+/* diagnostic build: a cell offset that cannot be one is recorded (stats[24..27]: tag, offset, previous offset, count) and the walk ends */
+#define QR_GUARD_POS(tag, p, prev, onbad) do { if (((p) & 31u) != 0u || (p) >= 0x10000000u) { \
+        if (atomicAdd(&stats[27], 1ull) == 0ull) { stats[24] = (tag); stats[25] = (p); stats[26] = (prev); } onbad; } } while (0)
+#else
+#define QR_GUARD_POS(tag, p, prev, onbad) do { } while (0)
+#endif
 #define LM(cond) __builtin_amdgcn_ballot_w64(cond)
 __device__ __forceinline__ bool lane_of(lm_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ bool any_lane(bool b) { return LM(b) != 0ull; }
@@ -367,16 +374,21 @@ __device__ __forceinline__ void cell_space(BaseP B, u32 op, u32 srf_off, float p
     }
 }
 
-template <bool SHADOW, bool DIV>
+template <bool SHADOW, bool DIV, bool WORLD = false>
 __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const SurfS &s, const Ray &r,
                                            float dd, WalkState &w, Hit &h)
 {
     typedef MK<DIV> K;
     typedef typename K::T mask_t;
-    /* ---- diff / ray in the surface's space, 1352-1556 ---- */
+    /* ---- diff / ray in the surface's space, 1352-1556 (WORLD: the list has world-space cells only) ---- */
     ClipIn<DIV> ci;
     ci.dmask = K::none(); ci.amask = 0;
-    cell_space(B, op, srf_off, s.pos0, s.pos1, s.pos2, r, w, ci.df, ci.ry);
+    if constexpr (WORLD)
+    {
+        ci.df.x = r.org.x - s.pos0; ci.df.y = r.org.y - s.pos1; ci.df.z = r.org.z - s.pos2;
+        ci.ry = r.dir;
+    }
+    else cell_space(B, op, srf_off, s.pos0, s.pos1, s.pos2, r, w, ci.df, ci.ry);
     /* a secondary ray on its own surface starts from the parent's local hit, 1352-1373 */
     const mask_t same = K::of(srf_off == r.osrf);
     if (K::any(same))
@@ -606,6 +618,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
         for (;;)
         {
             pos = __builtin_amdgcn_readfirstlane(pos);      /* wave-uniform by construction; says so to the compiler */
+            QR_GUARD_POS(1, pos, head, return);
             c = *(const QR_CONST u32x8 *)(B + pos);
             if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
             const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
@@ -781,6 +794,7 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
 #endif
             if (lane_of(adv))
             {
+                QR_GUARD_POS(2, pos, r.list, return);
                 const u32x4 a0 = *(const QR_CONST u32x4 *)(B + pos), a1 = *(const QR_CONST u32x4 *)(B + pos + 16),
                             b0 = *(const QR_CONST u32x4 *)(B + pos + 32), b1 = *(const QR_CONST u32x4 *)(B + pos + 48);
                 const u32 op = a0.x, srf_off = a0.y;
@@ -906,6 +920,29 @@ __device__ __forceinline__ int lanes_below(lm_t m)
  * walked does not matter.  Depth tests inside a range use the range's own bound; the best depth known for the ray when
  * the range was taken only feeds the conservative sphere culls.
  */
+/*
+ * One conservative test for either kind of cell (ours, not the reference's; a cell without QR_OPF_CULL carries R = +inf
+ * and fails none of it).  c1 = {centre, R}; r2 = the sphere's radius^2 the discriminant is taken against (solver cell:
+ * R^2; sphere volume: the volume's own sci_w), out2 = "origin outside" threshold (solver: 1.01 R^2; sphere volume: -1,
+ * always; other volume: +inf, never).  Solver cells use the RAY (b |b|: a sphere behind the origin is missed),
+ * volumes the LINE like AR_ptr (b b), plus `behind`.  Also returns the discriminant terms: a sphere volume is
+ * certainly entered when b2 - m >= rhs.
+ */
+__device__ __forceinline__ bool pool_cull(u32 srf, const u32x4 &c1, float r2, float out2, bool line, const Ray &r,
+                                          float dd, float dde, float dlen, float tbd, float &b2, float &m, float &rhs)
+{
+    const float R = u2f(c1.w);
+    const float ocx = u2f(c1.x) - r.org.x, ocy = u2f(c1.y) - r.org.y, ocz = u2f(c1.z) - r.org.z;
+    const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+    const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+    b2 = (line ? __builtin_fabsf(b) : b) * __builtin_fabsf(b);
+    m = oc2 * dde;
+    rhs = dd * (oc2 - r2);
+    const bool miss = ((oc2 > out2) & (b2 + m < rhs))
+                    | (__builtin_fmaf(-R, dlen, b) > tbd) | (__builtin_fmaf(R, dlen, b) < 0.0f);
+    return miss & (srf != r.osrf);
+}
+
 template <bool SHADOW>
 __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS
@@ -931,6 +968,12 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
     u32 give = 0;
     u32 p_op = 0, p_srf = 0, p_pos = 0;         /* the candidate cell the lane stands on (p_op == 0: none) */
     bool busy = active;
+#if defined(QR_STATS) && defined(QR_GUARD)
+    u32 g_prev = 0, g_how = 0;
+#define QR_G(x) x
+#else
+#define QR_G(x)
+#endif
     Hit lh; lh.t = 0.0f; lh.srf = 0; lh.side = 0; lh.loc = {0, 0, 0};
     u32 lh_pos = 0;
     P.key[lane] = SHADOW ? 0ull : (((unsigned long long)f2u(r.tmax) << 32) | 0xFFFFFFFFull);
@@ -987,6 +1030,7 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
             if (tk)
             {
                 owner = src; pos = g.y; iend = g.z; give = 0; busy = true;
+                QR_G(g_prev = g.z; g_how = 8;)
                 cr.org = {ox, oy, oz}; cr.dir = {dx, dy, dz}; cr.tmin = tmn; cr.tmax = tmx;
                 cr.osrf = osf; cr.oflg = ofl; cr.ploc = {px, py, pz};
                 dd = dx * dx + dy * dy + dz * dz;
@@ -1012,6 +1056,7 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
 #endif
             if (lane_of(adv))
             {
+                QR_GUARD_POS(3, pos, ((unsigned long long)g_prev << 32) | g_how, return);
                 const u32x4 a0 = *(const QR_CONST u32x4 *)(B + pos), a1 = *(const QR_CONST u32x4 *)(B + pos + 16),
                             b0 = *(const QR_CONST u32x4 *)(B + pos + 32), b1 = *(const QR_CONST u32x4 *)(B + pos + 48);
                 const u32 op = a0.x, srf_off = a0.y;
@@ -1019,44 +1064,41 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                 bool stop = op == 0;
                 if (SHADOW) stop = stop || ((const volatile u32 *)&P.key[owner])[0] != 0u;     /* somebody found the ray occluded */
                 if (stop) next = 0;
-                else if (op & QR_OPT_SOLVER)
-                {
-                    if (!(op & QR_OPF_CULL) || !div_culled(a0, a1, cr, dd, dde, dlen, w.tbd)) { p_op = op; p_srf = srf_off; p_pos = pos; }
-                    else if ((b0.x & QR_OPT_SOLVER) != 0 && pos + 32 < iend)
-                    {
-                        next = pos + 64;
-                        if (!(b0.x & QR_OPF_CULL) || !div_culled(b0, b1, cr, dd, dde, dlen, w.tbd)) { p_op = b0.x; p_srf = b0.y; p_pos = pos + 32; }
-                    }
-                }
-                else if (op & QR_OPT_BV)
-                {
-                    next = pos + 64;
-                    bool far = false;
-                    if (op & QR_OPF_CULL)
-                    {
-                        const float R = u2f(a1.w);
-                        const float ocx = u2f(a1.x) - cr.org.x, ocy = u2f(a1.y) - cr.org.y, ocz = u2f(a1.z) - cr.org.z;
-                        const float bb = __builtin_fmaf(ocz, cr.dir.z, __builtin_fmaf(ocy, cr.dir.y, ocx * cr.dir.x));
-                        far = (__builtin_fmaf(R, dlen, bb) < 0.0f) | (__builtin_fmaf(-R, dlen, bb) > w.tbd);
-                    }
-                    if (far) next = a0.z;
-                    else
-                    {
-                        V3 df, ry;
-                        cell_space(B, op, srf_off, u2f(b0.x), u2f(b0.y), u2f(b0.z), cr, w, df, ry);
-                        if (!bv_hit(ry, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w))) next = a0.z;
-                        else if (give <= pos) give = b0.w;          /* entered: a later child of this volume starts there */
-                    }
-                }
                 else
                 {
-                    const u32x4 p0 = *(const QR_CONST u32x4 *)(B + srf_off);
-                    V3 d;
-                    d.x = cr.org.x - u2f(p0.x); d.y = cr.org.y - u2f(p0.y); d.z = cr.org.z - u2f(p0.z);
-                    w.txyz = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, d);
-                    w.trijk = xform(B, srf_off, (op & QR_OPF_FULLM) != 0, cr.dir);
+                    const bool is_bv = (op & QR_OPT_BV) != 0;
+                    /* the array's end in a register of its own: hipcc 7.2 otherwise reuses a0.z's register for temporaries of
+                     * the exact test below and a lane that fails that test continues at a garbage offset (seen in the ISA,
+                     * caught by the QR_GUARD build) */
+                    u32 bv_end = a0.z;
+                    asm volatile("" : "+v"(bv_end));
+                    float b2, m, rhs;
+                    const bool culled = pool_cull(srf_off, a1, is_bv ? u2f(b1.w) : u2f(a0.z), u2f(a0.w), is_bv, cr, dd, dde, dlen, w.tbd, b2, m, rhs);
+                    if (is_bv)
+                    {
+                        next = pos + 64;
+                        bool enter = !culled;
+                        if (enter && !((op & QR_OPF_SPHBV) != 0 && b2 - m >= rhs))
+                        {
+                            /* AR_ptr itself: not a plain sphere, or the ray passes within rounding of its surface */
+                            V3 df;
+                            df.x = cr.org.x - u2f(b0.x); df.y = cr.org.y - u2f(b0.y); df.z = cr.org.z - u2f(b0.z);
+                            enter = bv_hit(cr.dir, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w));
+                        }
+                        if (!enter) next = bv_end;
+                        else if (give <= pos) give = b0.w;          /* entered: a later child of this volume starts there */
+                    }
+                    else if (!culled) { p_op = op; p_srf = srf_off; p_pos = pos; }
+                    else if ((b0.x & QR_OPT_SOLVER) != 0 && pos + 32 < iend)
+                    {
+                        /* second cell of the load */
+                        next = pos + 64;
+                        if (!pool_cull(b0.y, b1, u2f(b0.z), u2f(b0.w), false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
+                        { p_op = b0.x; p_srf = b0.y; p_pos = pos + 32; }
+                    }
                 }
                 if (next >= iend) next = 0;
+                QR_G(g_prev = pos; g_how = (op & 0xFFFFFu) | ((next == a0.z ? 1u : 0u) << 24) | ((next == pos + 64 ? 1u : 0u) << 25);)
                 pos = next;
             }
         }
@@ -1071,7 +1113,7 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                 SurfS s;
                 ld_surf_lane(B, p_srf, s);
                 const float tb = w.tbuf;
-                solve_cell<SHADOW, true>(B, p_op, p_srf, s, cr, dd, w, lh);
+                solve_cell<SHADOW, true, true>(B, p_op, p_srf, s, cr, dd, w, lh);
                 p_op = 0;
                 if (SHADOW)
                 {
@@ -1149,18 +1191,20 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
             const lm_t go = incoherent ? can_div : mine;
             pending &= ~go;
 #if QR_POOL
+            /* hand-over needs lists without transform state (QR_LISTF_WORLD) */
+            if ((go & LM((r.list & QR_LISTF_WORLD) == 0)) == 0)
             walk_pool<SHADOW>(B, lane_of(go), r, h, occluded
 #ifdef QR_STATS
                               , stats
 #endif
                               );
-#else
+            else
+#endif
             walk_div<SHADOW>(B, lane_of(go), r, h, occluded
 #ifdef QR_STATS
                              , stats
 #endif
                              );
-#endif
             continue;
         }
         }
