@@ -133,7 +133,9 @@ typedef struct qr_program_info
     uint32_t n_dropped;         /* snapshot cells that needed no device cell (markers)        */
     uint32_t n_clip_cells;      /* cells of clipper programs                                  */
     uint32_t n_sched;           /* wave-schedule entries (= waves of a whole-frame launch)    */
-    uint32_t reserved[3];
+    uint32_t n_grids;           /* shadow lists by hit position built for large planes        */
+    uint32_t n_grid_lists;      /* lists in them                                              */
+    uint32_t reserved[1];
 } qr_program_info;
 int qr_program_stats(const void *blob, uint64_t size, qr_program_info *info);
 

@@ -142,10 +142,168 @@ void qr_bound_spheres(const qr_scene_view &v, std::vector<BSphere> &out)
 
 namespace {
 
+#ifndef QR_FLAT_LIST_MAX
+#define QR_FLAT_LIST_MAX 128
+#endif
+
+struct ListFilter
+{
+    const qr_scene_view &v;
+    const std::vector<BSphere> &bs;
+    std::vector<qr_elem> &E;                /* grows */
+    struct Node { int e; int si; int last; bool head; BSphere bound; bool bounded; };
+    std::vector<Node> ch;
+    int n_real = 0;                         /* surfaces in the chain */
+
+    /* the chain at `clist` of E (which also receives the filtered chains: elements are read by index only) */
+    ListFilter(const qr_scene_view &v_, const std::vector<BSphere> &bs_, std::vector<qr_elem> &E_, int clist)
+        : v(v_), bs(bs_), E(E_)
+    {
+        std::vector<int> pos_of(E.size(), -1);
+        for (int e = clist; e != QR_NULL; e = E[e].next) { pos_of[e] = (int)ch.size(); ch.push_back(Node{e, E[e].simd, -1, false, {}, false}); }
+        const int n = (int)ch.size();
+        n_real = 0;
+        for (int i = 0; i < n; i++) if (is_real(v.srf[ch[i].si])) n_real++;
+        for (int i = 0; i < n; i++)
+        {
+            const qr_elem el = E[ch[i].e];
+            const qr_surface &s = v.srf[el.simd];
+            const bool head = (el.kind & 3) == 1 || s.srf_t[3] < 0;
+            ch[i].head = head && el.data != QR_NULL && pos_of[el.data] >= i;
+            if (ch[i].head) ch[i].last = pos_of[el.data];
+            else { ch[i].bound = bs[el.simd]; ch[i].bounded = is_real(s) && bs[el.simd].r < 1e18f; }
+        }
+        /* union spheres of arrays, innermost first (a later head nests inside an earlier one) */
+        for (int i = n - 1; i >= 0; i--)
+        {
+            if (!ch[i].head) continue;
+            bool ok = true; int first = -1;
+            for (int k = i + 1; k <= ch[i].last; k++)
+                if (!ch[k].head) { if (!is_real(v.srf[ch[k].si])) continue; if (!ch[k].bounded) ok = false; else if (first < 0) first = k; }
+            ch[i].bounded = false;
+            if (!ok || first < 0) continue;
+            const BSphere &c0 = ch[first].bound;
+            double R = 0.0;
+            for (int k = i + 1; k <= ch[i].last; k++)
+                if (!ch[k].head && ch[k].bounded)
+                {
+                    const BSphere &m = ch[k].bound;
+                    const double dx = (double)m.c[0] - c0.c[0], dy = (double)m.c[1] - c0.c[1], dz = (double)m.c[2] - c0.c[2];
+                    const double d = __builtin_sqrt(dx * dx + dy * dy + dz * dz) + (double)m.r;
+                    if (d > R) R = d;
+                }
+            ch[i].bound = c0; ch[i].bound.r = (float)(R * 1.0001 + 1e-4);
+            ch[i].bounded = true;
+        }
+    }
+
+    /* keep(sphere, bounded) -> may a surface with this bound matter; returns the new list's head */
+    template <typename Pred>
+    int filter(Pred keep)
+    {
+        struct Open { int idx; int out; int last; };
+        std::vector<Open> open;
+        int head = QR_NULL, tail = QR_NULL;
+        auto emit = [&](int src_e, int data) {
+            qr_elem c = E[src_e];
+            c.data = data; c.next = QR_NULL;
+            E.push_back(c);
+            const int ix = (int)E.size() - 1;
+            if (tail != QR_NULL) E[tail].next = ix; else head = ix;
+            tail = ix;
+            return ix;
+        };
+        auto close_until = [&](int i) {
+            while (!open.empty() && open.back().last < i)
+            {
+                if (open.back().out != QR_NULL) E[open.back().out].data = tail;      /* last kept member */
+                open.pop_back();
+            }
+        };
+        const int n = (int)ch.size();
+        for (int i = 0; i < n; )
+        {
+            close_until(i);
+            const Node &nd = ch[i];
+            if (nd.head)
+            {
+                if (nd.bounded && !keep(nd.bound, true)) { i = nd.last + 1; continue; }      /* prune the array */
+                open.push_back(Open{i, QR_NULL, nd.last});
+                i++;
+                continue;
+            }
+            const bool real = is_real(v.srf[nd.si]);
+            if (!real || keep(nd.bound, nd.bounded))
+            {
+                for (Open &o : open) if (o.out == QR_NULL) o.out = emit(ch[o.idx].e, QR_NULL);
+                emit(nd.e, E[nd.e].data);
+            }
+            i++;
+        }
+        close_until(n);
+        /* a list that keeps only a handful of surfaces does not need their bounding-volume elements (AR_ptr elements
+         * only skip work, tracer.cpp:3955-4054): written flat it is a fraction of the cells.  Trnode elements stay. */
+        int kept = 0;
+        for (int e = head; e != QR_NULL; e = E[e].next) if (is_real(v.srf[E[e].simd])) kept++;
+        if (kept <= QR_FLAT_LIST_MAX)
+        {
+            int nh = QR_NULL, nt = QR_NULL;
+            for (int e = head; e != QR_NULL; )
+            {
+                const int nx = E[e].next;
+                if ((E[e].kind & 3) != 1)
+                {
+                    if (nt != QR_NULL) E[nt].next = e; else nh = e;
+                    nt = e; E[e].next = QR_NULL;
+                }
+                e = nx;
+            }
+            head = nh;
+        }
+        return head;
+    }
+};
+
+
+/*
+ * May a surface with bounding sphere x stand between the point lp and some point of the sphere (sc, sr)?  The hull of
+ * the light position and that sphere: at parameter tau in [0,1] along the axis a sphere of radius tau sr; x meets it iff
+ * min_tau |c - axis(tau)| - tau sr <= r_x; the minimum is at least d_min sqrt(1 - rho^2) - tc sr with d_min the
+ * distance to the axis segment and tc its parameter (bbox_shad's role, rtgeom.cpp:1004).
+ */
+struct HullPred
+{
+    double lp[3], D[3], D2, Dl, sr, shrink; bool all;
+    HullPred(const float *light_pos, const double *sc, double sr_) : sr(sr_)
+    {
+        for (int k = 0; k < 3; k++) { lp[k] = light_pos[k]; D[k] = sc[k] - lp[k]; }
+        D2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2]; Dl = __builtin_sqrt(D2);
+        const double rho = Dl > 0.0 ? sr / Dl : 2.0;
+        all = !(rho < 0.95);
+        shrink = all ? 0.0 : __builtin_sqrt(1.0 - rho * rho);
+    }
+    bool operator()(const BSphere &x, bool bounded) const
+    {
+        if (all || !bounded) return true;
+        const double P[3] = { x.c[0] - lp[0], x.c[1] - lp[1], x.c[2] - lp[2] };
+        const double t = (P[0] * D[0] + P[1] * D[1] + P[2] * D[2]) / D2;
+        const double tc = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double q[3] = { P[0] - tc * D[0], P[1] - tc * D[1], P[2] - tc * D[2] };
+        const double dmin = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        const double xr = (double)x.r * 1.001 + 1e-3;
+        if (t > 1.0 + (sr + xr) / Dl + 1e-3) return false;          /* behind the surface */
+        return dmin * shrink <= xr + tc * sr * 1.001 + 1e-3;
+    }
+};
+
 struct Builder
 {
     const qr_scene_view &v;
     const std::vector<qr_elem> &E;          /* cells: the snapshot's, or the binning pass's                 */
+    std::vector<qr_elem> *Egrow = nullptr;  /* the same vector when the compiler may append filtered chains (shadow grids) */
+    std::vector<int> light_user;            /* light list head -> the one surface that uses it, -2 several, -1 none */
+    int grid_min = 256;                     /* shadow lists with at least this many surfaces get a grid       */
+    uint32_t n_grids = 0, n_grid_lists = 0;
     const std::vector<BSphere> &bs;
     const int cull_mode;
     std::vector<uint8_t> &blob;
@@ -187,6 +345,13 @@ struct Builder
     uint32_t compile_list(int head)
     {
         if (head == QR_NULL) return 0;
+        if (E.size() + 1 > list_off.size())
+        {
+            /* chains appended by the shadow grids */
+            const size_t n1 = E.size() + 1;
+            list_off.resize(n1, 0); light_off.resize(n1, 0); list_heavy.resize(n1, 0);
+            chain_pos.resize(n1, 0); chain_stamp.resize(n1, -1);
+        }
         if (list_off[head]) return list_off[head];
         ch.clear();
         stamp++;
@@ -476,6 +641,59 @@ struct Builder
     }
 
     /* ---- light lists ---- */
+    /*
+     * Shadow lists by hit position for surface `si` (an untransformed plane with a finite clip rectangle) and light `lg`,
+     * whose shadow list `sh` holds many surfaces: CGrid, qr_program.h.  Returns the record's offset | QR_LISTF_GRID, or 0.
+     */
+    uint32_t compile_grid(int si, int lg, int sh)
+    {
+        const qr_surface &s = v.srf[si];
+        if (!is_real(s) || s.srf_t[0] != 1 || s.has_trm != 0 || s.shift != 0) return 0;
+        const int k = (int)((s.axes >> 4) & 3);
+        if (k > 2) return 0;
+        const int a = k == 0 ? 1 : 0, b = k == 2 ? 1 : 2;
+        const bool fin = (s.minmax_t & (1u << a)) && (s.minmax_t & (1u << (3 + a))) && (s.minmax_t & (1u << b)) && (s.minmax_t & (1u << (3 + b)));
+        if (!fin) return 0;
+        const double lo_a = s.min[a], hi_a = s.max[a], lo_b = s.min[b], hi_b = s.max[b];
+        const double ea = hi_a - lo_a, eb = hi_b - lo_b;
+        if (!(ea > 1e-3) || !(eb > 1e-3) || !(ea < 1e18) || !(eb < 1e18)) return 0;
+        /* long enough to be worth it? */
+        int n_real = 0;
+        for (int e = sh; e != QR_NULL && n_real < grid_min; e = E[e].next) if (is_real(v.srf[E[e].simd])) n_real++;
+        if (n_real < grid_min) return 0;
+        ListFilter lf(v, bs, *Egrow, sh);
+        const double cell = (ea > eb ? ea : eb) / (double)QR_GRID_MAX;
+        auto cells = [&](double ext) { int n = (int)(ext / cell + 0.5); return n < 1 ? 1 : (n > (int)QR_GRID_MAX ? (int)QR_GRID_MAX : n); };
+        const int nx = cells(ea), ny = cells(eb);
+        CGrid g;
+        g.nx = (uint32_t)nx; g.ny = (uint32_t)ny; g.comps = (uint32_t)a | ((uint32_t)b << 2);
+        g.org_a = (float)lo_a; g.org_b = (float)lo_b;
+        g.inv_a = (float)(nx / ea); g.inv_b = (float)(ny / eb);
+        std::vector<uint32_t> table((size_t)nx * ny, 0u);
+        const double ca = ea / nx, cb = eb / ny;
+        /* cells overlap: the kernel's cell index comes from the fp32 local hit (error far below a thousandth of a cell
+         * at any sane scale), and the shadow ray starts at the world-space hit, the same point up to rounding */
+        const double pad_a = 2e-3 * ca + 1e-3, pad_b = 2e-3 * cb + 1e-3;
+        const double pr = __builtin_sqrt((0.5 * ca + pad_a) * (0.5 * ca + pad_a) + (0.5 * cb + pad_b) * (0.5 * cb + pad_b)) + 1e-3;
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++)
+            {
+                double pc[3] = { s.pos[0], s.pos[1], s.pos[2] };
+                pc[a] += lo_a + (i + 0.5) * ca; pc[b] += lo_b + (j + 0.5) * cb;
+                const HullPred pred(v.lgt[lg].pos, pc, pr);
+                const int h = lf.filter(pred);
+                table[(size_t)j * nx + i] = compile_list(h);
+                n_grid_lists++;
+            }
+        g.table = alloc(table.size() * 4, 4);
+        memcpy(at<uint32_t>(g.table), table.data(), table.size() * 4);
+        const uint32_t off = alloc(sizeof(CGrid), 32);
+        *at<CGrid>(off) = g;
+        n_grids++;
+        any_long = true;                /* the kernel instance that knows grids */
+        return off | QR_LISTF_GRID;
+    }
+
     uint32_t compile_lights(int head)
     {
         if (head == QR_NULL) return 0;
@@ -485,7 +703,10 @@ struct Builder
         {
             CLight l;
             l.lgt = o_lgt + (uint32_t)E[e].simd * (uint32_t)sizeof(qr_light);
-            l.shadow = compile_list(E[e].data);
+            const int sh = E[e].data, lg = E[e].simd;       /* copies: compile_grid appends to E */
+            l.shadow = compile_list(sh);
+            if (Egrow != nullptr && light_user[head] >= 0 && sh != QR_NULL)
+                if (const uint32_t g = compile_grid(light_user[head], lg, sh)) l.shadow = g;
             ls.push_back(l);
         }
         ls.back().lgt |= QR_CLIGHT_LAST;
@@ -511,7 +732,36 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
     {
         out.blob.reserve(sizeof(DevHeader) + (size_t)(n_srf + 1) * (sizeof(DSurf) + sizeof(DShade)) + (size_t)(n_mat + 1) * sizeof(qr_material)
                          + (size_t)n_tex * 4 + T.size() * 4 + E.size() * 80 + (size_t)frm.frm_w * frm.frm_h / 8 + 65536);
-        Builder b(v, E, bs, cull_mode, out.blob);
+        /* shadow grids (CGrid) append filtered chains to the cell array: work on a copy then.  Only scenes with long
+         * shadow lists on clipped planes get any, so the per-frame compile of the engine's scenes never copies. */
+        const char *ge = getenv("QR_GRID");
+        const int grid_min = ge ? atoi(ge) : 256;           /* 0 turns the grids off */
+        std::vector<qr_elem> Eg;
+        bool want_grids = false;
+        if (grid_min > 0 && E.size() >= (size_t)grid_min)
+            for (int i = 0; i < n_srf && !want_grids; i++)
+            {
+                const qr_surface &q = v.srf[i];
+                if (is_real(q) && q.srf_t[0] == 1 && q.has_trm == 0 && q.shift == 0 && (q.lst[0] != QR_NULL || q.lst[2] != QR_NULL)) want_grids = true;
+            }
+        if (want_grids) Eg = E;
+        Builder b(v, want_grids ? Eg : E, bs, cull_mode, out.blob);
+        if (want_grids)
+        {
+            b.Egrow = &Eg; b.grid_min = grid_min;
+            b.light_user.assign(E.size() + 1, -1);
+            for (int i = 0; i < n_srf; i++)
+            {
+                const qr_surface &q = v.srf[i];
+                if (!is_real(q)) continue;
+                for (int k = 0; k < 2; k++)
+                {
+                    const int h = q.lst[k * 2];
+                    if (h == QR_NULL) continue;
+                    b.light_user[h] = (b.light_user[h] == -1 || b.light_user[h] == i) ? i : -2;
+                }
+            }
+        }
         /* fixed sections; index n_* is a zero record so that masked-off lanes may read it */
         b.alloc(sizeof(DevHeader), 256);
         b.o_srf = b.alloc((size_t)(n_srf + 1) * sizeof(DSurf), 128);
@@ -680,9 +930,10 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         out.off_srf = b.o_srf; out.off_shade = b.o_shd; out.off_mat = b.o_mat; out.off_lgt = b.o_lgt; out.off_tex = b.o_tex; out.off_tiles = o_til;
         out.n_srf = (uint32_t)n_srf; out.n_mat = (uint32_t)n_mat; out.n_lgt = (uint32_t)n_lgt; out.n_tex = (uint32_t)n_tex; out.n_tiles = (uint32_t)T.size();
         out.off_lists = o_ord + (uint32_t)(n_sched * 8 + 16);
-        b.st.bytes = out.blob.size();
+        b.st.bytes = out.blob.size(); b.st.n_grids = b.n_grids; b.st.n_grid_lists = b.n_grid_lists;
         out.stats = b.st;
         out.has_long_lists = b.any_long;
+        out.has_grids = b.n_grids != 0;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
     return qr_program_verify(out, err);
@@ -793,7 +1044,20 @@ int qr_program_verify(const QrProgram &p, std::string &err)
                     const CLight *l = (const CLight *)(b.data() + o);
                     const uint32_t lo = l->lgt & ~QR_CLIGHT_LAST;
                     if (!in_arr(lo, p.off_lgt, p.n_lgt, sizeof(qr_light)) || lo == p.off_lgt + p.n_lgt * (uint32_t)sizeof(qr_light)) return bad("light offset");
-                    if (const char *m = check_list(l->shadow)) return bad(m);
+                    if (l->shadow & QR_LISTF_GRID)
+                    {
+                        /* shadow lists by hit position: record, table and every list in it */
+                        const uint32_t go = l->shadow & ~31u;
+                        if ((l->shadow & 31u) != QR_LISTF_GRID || go < p.off_lists || (size_t)go + sizeof(CGrid) > limit) return bad("shadow grid offset");
+                        const CGrid *g = (const CGrid *)(b.data() + go);
+                        if (g->nx < 1 || g->nx > QR_GRID_MAX || g->ny < 1 || g->ny > QR_GRID_MAX) return bad("shadow grid size");
+                        const uint32_t ca = g->comps & 3u, cb = (g->comps >> 2) & 3u;
+                        if ((g->comps >> 4) || ca > 2 || cb > 2 || ca == cb) return bad("shadow grid components");
+                        if ((g->table & 3) || g->table < p.off_lists || (size_t)g->table + (size_t)g->nx * g->ny * 4 > limit) return bad("shadow grid table");
+                        const uint32_t *tb = (const uint32_t *)(b.data() + g->table);
+                        for (uint32_t q = 0; q < g->nx * g->ny; q++) if (const char *m = check_list(tb[q])) return bad(m);
+                    }
+                    else if (const char *m = check_list(l->shadow)) return bad(m);
                     if (l->lgt & QR_CLIGHT_LAST) break;
                 }
             }
@@ -832,6 +1096,7 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
     memset(info, 0, sizeof(*info));
     info->bytes = p.stats.bytes; info->n_lists = p.stats.n_lists; info->n_cells = p.stats.n_cells;
     info->n_dropped = p.stats.n_dropped; info->n_clip_cells = p.stats.n_clip_cells; info->n_sched = p.n_sched;
+    info->n_grids = p.stats.n_grids; info->n_grid_lists = p.stats.n_grid_lists;
     return QR_OK;
 }
 
@@ -858,124 +1123,6 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
 #ifndef QR_FLAT_LIST_MAX
 #define QR_FLAT_LIST_MAX 128
 #endif
-
-namespace {
-
-struct ListFilter
-{
-    const qr_scene_view &v;
-    const std::vector<BSphere> &bs;
-    std::vector<qr_elem> &E;                /* grows */
-    struct Node { int e; int si; int last; bool head; BSphere bound; bool bounded; };
-    std::vector<Node> ch;
-
-    ListFilter(const qr_scene_view &v_, const std::vector<BSphere> &bs_, std::vector<qr_elem> &E_, int clist)
-        : v(v_), bs(bs_), E(E_)
-    {
-        std::vector<int> pos_of((size_t)v.hdr->n_elm, -1);
-        for (int e = clist; e != QR_NULL; e = v.elm[e].next) { pos_of[e] = (int)ch.size(); ch.push_back(Node{e, v.elm[e].simd, -1, false, {}, false}); }
-        const int n = (int)ch.size();
-        for (int i = 0; i < n; i++)
-        {
-            const qr_elem &el = v.elm[ch[i].e];
-            const qr_surface &s = v.srf[el.simd];
-            const bool head = (el.kind & 3) == 1 || s.srf_t[3] < 0;
-            ch[i].head = head && el.data != QR_NULL && pos_of[el.data] >= i;
-            if (ch[i].head) ch[i].last = pos_of[el.data];
-            else { ch[i].bound = bs[el.simd]; ch[i].bounded = is_real(s) && bs[el.simd].r < 1e18f; }
-        }
-        /* union spheres of arrays, innermost first (a later head nests inside an earlier one) */
-        for (int i = n - 1; i >= 0; i--)
-        {
-            if (!ch[i].head) continue;
-            bool ok = true; int first = -1;
-            for (int k = i + 1; k <= ch[i].last; k++)
-                if (!ch[k].head) { if (!is_real(v.srf[ch[k].si])) continue; if (!ch[k].bounded) ok = false; else if (first < 0) first = k; }
-            ch[i].bounded = false;
-            if (!ok || first < 0) continue;
-            const BSphere &c0 = ch[first].bound;
-            double R = 0.0;
-            for (int k = i + 1; k <= ch[i].last; k++)
-                if (!ch[k].head && ch[k].bounded)
-                {
-                    const BSphere &m = ch[k].bound;
-                    const double dx = (double)m.c[0] - c0.c[0], dy = (double)m.c[1] - c0.c[1], dz = (double)m.c[2] - c0.c[2];
-                    const double d = __builtin_sqrt(dx * dx + dy * dy + dz * dz) + (double)m.r;
-                    if (d > R) R = d;
-                }
-            ch[i].bound = c0; ch[i].bound.r = (float)(R * 1.0001 + 1e-4);
-            ch[i].bounded = true;
-        }
-    }
-
-    /* keep(sphere, bounded) -> may a surface with this bound matter; returns the new list's head */
-    template <typename Pred>
-    int filter(Pred keep)
-    {
-        struct Open { int idx; int out; int last; };
-        std::vector<Open> open;
-        int head = QR_NULL, tail = QR_NULL;
-        auto emit = [&](int src_e, int data) {
-            qr_elem c = v.elm[src_e];
-            c.data = data; c.next = QR_NULL;
-            E.push_back(c);
-            const int ix = (int)E.size() - 1;
-            if (tail != QR_NULL) E[tail].next = ix; else head = ix;
-            tail = ix;
-            return ix;
-        };
-        auto close_until = [&](int i) {
-            while (!open.empty() && open.back().last < i)
-            {
-                if (open.back().out != QR_NULL) E[open.back().out].data = tail;      /* last kept member */
-                open.pop_back();
-            }
-        };
-        const int n = (int)ch.size();
-        for (int i = 0; i < n; )
-        {
-            close_until(i);
-            const Node &nd = ch[i];
-            if (nd.head)
-            {
-                if (nd.bounded && !keep(nd.bound, true)) { i = nd.last + 1; continue; }      /* prune the array */
-                open.push_back(Open{i, QR_NULL, nd.last});
-                i++;
-                continue;
-            }
-            const bool real = is_real(v.srf[nd.si]);
-            if (!real || keep(nd.bound, nd.bounded))
-            {
-                for (Open &o : open) if (o.out == QR_NULL) o.out = emit(ch[o.idx].e, QR_NULL);
-                emit(nd.e, v.elm[nd.e].data);
-            }
-            i++;
-        }
-        close_until(n);
-        /* a list that keeps only a handful of surfaces does not need their bounding-volume elements (AR_ptr elements
-         * only skip work, tracer.cpp:3955-4054): written flat it is a fraction of the cells.  Trnode elements stay. */
-        int kept = 0;
-        for (int e = head; e != QR_NULL; e = E[e].next) if (is_real(v.srf[E[e].simd])) kept++;
-        if (kept <= QR_FLAT_LIST_MAX)
-        {
-            int nh = QR_NULL, nt = QR_NULL;
-            for (int e = head; e != QR_NULL; )
-            {
-                const int nx = E[e].next;
-                if ((E[e].kind & 3) != 1)
-                {
-                    if (nt != QR_NULL) E[nt].next = e; else nh = e;
-                    nt = e; E[e].next = QR_NULL;
-                }
-                e = nx;
-            }
-            head = nh;
-        }
-        return head;
-    }
-};
-
-} // namespace
 
 int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, std::string &err)
 {

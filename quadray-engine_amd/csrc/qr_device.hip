@@ -192,7 +192,7 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     s->n_cells = n_cells;
     {
         const char *dv = getenv("QR_DIV");          /* QR_DIV=0 / 1 forces the kernel instance (experiments, tests) */
-        s->divk = dv ? atoi(dv) != 0 : prog.has_long_lists;
+        s->divk = (dv ? atoi(dv) != 0 : prog.has_long_lists) || prog.has_grids;      /* only that instance knows shadow grids */
     }
     s->lp.depth = frm.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : frm.depth;
     s->lp.row_begin = 0; s->lp.row_end = frm.frm_h;
@@ -798,7 +798,7 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         lp.row_begin = (int32_t)c.prog.block_row[k]; lp.row_end = (int32_t)c.prog.block_row[k + 1];
         if (lp.n_blocks > 0)
         {
-            if (c.prog.has_long_lists)
+            if (c.prog.has_long_lists || c.prog.has_grids)
                 hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
             else

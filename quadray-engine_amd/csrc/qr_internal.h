@@ -26,7 +26,7 @@ struct BSphere { float c[3]; float r; };    /* conservative world-space bounding
 
 #define QR_SCHED_PER_LANE 0xFFFFFFFEu       /* schedule entry: the footprint straddles tiles, look the list up per pixel */
 
-struct QrProgramStats { uint64_t bytes; uint32_t n_lists, n_cells, n_dropped, n_clip_cells; };
+struct QrProgramStats { uint64_t bytes; uint32_t n_lists, n_cells, n_dropped, n_clip_cells, n_grids, n_grid_lists; };
 
 struct QrProgram
 {
@@ -37,6 +37,7 @@ struct QrProgram
     uint32_t off_srf = 0, off_shade = 0, off_mat = 0, off_lgt = 0, off_tex = 0, off_tiles = 0, off_lists = 0;
     uint32_t n_srf = 0, n_mat = 0, n_lgt = 0, n_tex = 0, n_tiles = 0;
     QrProgramStats stats = {};
+    bool has_grids = false;         /* some light-list entry points at a CGrid: needs the same kernel instance */
     bool has_long_lists = false;    /* some list is flagged QR_LISTF_LONG: the launch uses the kernel instance with the per-lane walk */
     /* sched_blocks > 1: the schedule is grouped by horizontal block of the frame (heavy footprints first inside
      * every block); entries [block_first[k], block_first[k+1]) render rows [block_row[k], block_row[k+1]) */

@@ -77,7 +77,26 @@ struct CBvExt
 #define QR_LISTF_DIV   1u       /* no cell has a clipper program: the per-lane walk may take this list      */
 #define QR_LISTF_LONG  2u       /* a long hierarchy (bounding-volume arrays, many cells): rays part ways on it */
 #define QR_LISTF_WORLD 4u       /* every cell reads the world-space ray: no trnode cell, no QR_OPF_CACHED / QR_OPF_OWN cell */
+#define QR_LISTF_GRID  8u       /* only in CLight::shadow: the offset is that of a CGrid, the shadow list depends on where the
+                                 * surface was hit                                                                        */
 #define QR_LIST_OFF(x) ((x) & ~31u)
+
+/*
+ * Shadow lists of a LARGE surface by hit position (ours; the reference keeps one shadow list per surface and light, so a
+ * ground plane under 10 000 objects gets all of them for every shadow ray).  For an untransformed plane with a finite
+ * clip rectangle the compiler cuts the rectangle into nx x ny cells and filters the surface's shadow list once per cell:
+ * what can stand between the light and that cell (qr_compile.cpp, HullPred).  The kernel picks the cell from the local
+ * hit: cell = floor((loc[comp] - org) * inv), clamped.  Cells overlap by a margin far above the rounding of `loc`.
+ */
+struct CGrid                    /* 32 B, 32-byte aligned */
+{
+    uint32_t table;             /* byte offset of nx * ny list offsets (row-major, b major; 0 = nothing can shadow that cell) */
+    uint32_t nx, ny;            /* cells along component a / b, 1..QR_GRID_MAX each                                       */
+    uint32_t comps;             /* a | b << 2: which components of the local hit span the plane                           */
+    float    org_a, org_b;      /* local coordinate of the rectangle's low corner                                         */
+    float    inv_a, inv_b;      /* cells per unit                                                                         */
+};
+#define QR_GRID_MAX 64u
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
 

@@ -195,7 +195,27 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         }
         Ray sr;
         sr.org = hit; sr.dir = L; sr.tmin = 0.0f; sr.tmax = lg->t_max;
-        sr.list = has ? cl.shadow : 0u; sr.osrf = hsrf; sr.oflg = side; sr.ploc = h.loc;
+        u32 sl = has ? cl.shadow : 0u;
+        if constexpr (DIVK)
+        {
+            /* shadow lists by hit position (CGrid, qr_program.h): large clipped planes of scenes with long lists */
+            if (any_lane((sl & QR_LISTF_GRID) != 0))
+            {
+                if (sl & QR_LISTF_GRID)
+                {
+                    const CGrid *__restrict__ gr = (const CGrid *)(G + (sl & ~31u));
+                    const u32 cp = gr->comps;
+                    const float la = (cp & 3u) == 0 ? h.loc.x : ((cp & 3u) == 1 ? h.loc.y : h.loc.z);
+                    const float lb = ((cp >> 2) & 3u) == 0 ? h.loc.x : (((cp >> 2) & 3u) == 1 ? h.loc.y : h.loc.z);
+                    int ia = cvt_floor((la - gr->org_a) * gr->inv_a), ib = cvt_floor((lb - gr->org_b) * gr->inv_b);
+                    const int nx = (int)gr->nx, ny = (int)gr->ny;
+                    ia = ia < 0 ? 0 : (ia >= nx ? nx - 1 : ia);
+                    ib = ib < 0 ? 0 : (ib >= ny ? ny - 1 : ib);
+                    sl = *(const u32 *)(G + (gr->table + (u32)(ib * nx + ia) * 4u));
+                }
+            }
+        }
+        sr.list = sl; sr.osrf = hsrf; sr.oflg = side; sr.ploc = h.loc;
         Hit sh; bool occ;
         if (COUNT) { if (lm) cnt.shadow++; }
         if (QR_KNOB(2)) lm = false;
