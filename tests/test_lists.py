@@ -45,6 +45,31 @@ def test_built_lists_replace_the_generators_own(qr, oracle):
     assert cb["flops"] <= 1.02 * ca["flops"] and cb["flops"] < cg["flops"]
 
 
+def test_compiler_builds_shadow_grids_for_large_planes_only(qr):
+    """Shadow lists by hit position (CGrid, csrc/qr_program.h): one grid per light for the clipped ground plane whose
+    shadow lists hold hundreds of surfaces -- when its light list is its own (the list-building pass's output) -- and
+    none for the engine's scenes, for a light list that several surfaces share, or with QR_GRID=0.  The image is verified
+    by the compiler either way (qr_program_verify walks every grid table entry)."""
+    import os
+    kw = dict(n_objects=600, width=160, height=90, depth=3, box=40.0)
+    built = qr.build_lists(_synth().make_scene(shadow_lists=False, **kw))
+    info = qr.program_stats(built)
+    assert info.n_grids == 4 and info.n_grid_lists == 4 * 64 * 64
+    assert qr.program_stats(_synth().make_scene(shadow_lists=False, **kw)).n_grids == 0      # one light list for everybody
+    assert qr.program_stats(load_blob("demo01_160")).n_grids == 0
+    os.environ["QR_GRID"] = "0"
+    try:
+        off = qr.program_stats(built)
+    finally:
+        del os.environ["QR_GRID"]
+    assert off.n_grids == 0 and off.n_cells < info.n_cells
+    os.environ["QR_GRID"] = "100000"                                         # threshold above the list's length
+    try:
+        assert qr.program_stats(built).n_grids == 0
+    finally:
+        del os.environ["QR_GRID"]
+
+
 def test_build_lists_rejects_snapshot_without_global_list(qr):
     import struct
     b = bytearray(load_blob("demo01_160"))

@@ -120,12 +120,16 @@ def test_gpu_scene_without_objects(qr, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "1"}, {"QR_BIN_TILE": "8x8"}])
+@pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "1"}, {"QR_BIN_TILE": "8x8"},
+                                 {"QR_GRID": "0"}, {"QR_GRID": "64", "QR_CULL": "0"}])
 def test_gpu_synth_build_variants_match_oracle(qr, oracle, env):
     """Upload-time variants of the compiled scene: no bounding-sphere cull cells, cull on planes only, 8x8 tiles
-    from the binning pass: same pixels, hit ids and ray counts as the oracle."""
+    from the binning pass, without / with a lower threshold for the shadow lists by hit position: same pixels, hit ids
+    and ray counts as the oracle."""
     import torch
     blob = _synth().make_scene(**MID)
+    if "QR_GRID" in env:
+        blob = qr.build_lists(_synth().make_scene(shadow_lists=False, **MID))     # own light list per surface: grids apply
     os.environ.update(env)
     try:
         scn = qr.Scene(blob, rebin_tiles=True)
