@@ -144,3 +144,46 @@ def test_gpu_synth_build_variants_match_oracle(qr, oracle, env):
     _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
     _, c = scn.render_count()
     assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}
+
+
+def _recamera(blob, seed, scale):
+    """The snapshot's camera moved and turned at random (same rotation for view, horizontal and vertical vectors)."""
+    import struct
+    rng = np.random.default_rng(seed)
+    b = bytearray(blob)
+    off_frame = struct.unpack_from("<I", b, 4 * 10)[0]
+    fr = np.frombuffer(b, dtype=np.float32, count=49, offset=off_frame).copy()
+    a = rng.normal(size=3); a /= np.linalg.norm(a)
+    th = rng.uniform(0.0, 0.6)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32)
+    for o in (1, 4, 7):
+        fr[o:o + 3] = R @ fr[o:o + 3]
+    fr[25:28] += rng.uniform(-scale, scale, size=3).astype(np.float32)
+    b[off_frame:off_frame + 196] = fr.tobytes()
+    return bytes(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gpu_synth_10k_objects_match_oracle(qr, oracle, seed):
+    """All 10 000 objects of BASELINE.json config 5 at frame sizes the oracle finishes in seconds (1920x1080 / 640x360, depth 4),
+    lists from the product's list-building pass as in bench.py: the per-lane walk with work hand-over (walk_pool), the
+    shadow lists by hit position on the ground plane (CGrid) and the binning pass against the oracle, which knows
+    none of them -- the original camera and two random ones (seed > 0: also from inside the object cloud)."""
+    import torch
+    w, h = (1920, 1080) if seed == 0 else (640, 360)
+    blob = qr.build_lists(_synth().make_scene(shadow_lists=False, width=w, height=h))
+    if seed:
+        blob = _recamera(blob, 77 * seed, 30.0)
+    assert qr.program_stats(blob).n_grids == 4
+    scn = qr.Scene(blob, rebin_tiles=True)
+    frame = scn.new_frame(); ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids); torch.cuda.synchronize()
+    o_frame, o_ids, _ = oracle.render(blob, threads=16, want_ids=True)
+    out = frame.cpu().numpy().view(np.uint32)
+    assert int((out != o_frame).sum()) == 0
+    assert (ids.cpu().numpy() == o_ids).all()
+    _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
+    _, c = scn.render_count()
+    assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}
