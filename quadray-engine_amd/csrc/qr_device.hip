@@ -479,6 +479,7 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
                 st[9], st[10], st[9] ? (double)st[10] / st[9] : 0.0, st[10] ? (double)st[11] / st[10] : 0.0,
                 st[9] ? (double)st[15] / st[9] : 0.0, st[22], st[16] ? (double)st[21] / st[16] : 0.0);
         fprintf(stderr, "QR_STATS ranges handed over %llu\n", st[23]);
+        fprintf(stderr, "QR_STATS outer rounds %llu: %.1f lanes tracing, %.1f lanes not finished\n", st[28], st[28] ? (double)st[29] / st[28] : 0.0, st[28] ? (double)st[30] / st[28] : 0.0);
         const char *nm[3] = { "shadow", "primary", "secondary" };
         for (int k = 0; k < 3; k++)
             fprintf(stderr, "QR_STATS %s: walks %llu elem-iterations %llu (%.1f per walk, %.0f%% culled) active lanes per iteration %.1f\n", nm[k],

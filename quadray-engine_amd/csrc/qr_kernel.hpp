@@ -314,6 +314,12 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     while (any_lane(mode != 2))
     {
         const bool tr = mode == 0;
+#ifdef QR_STATS
+        {
+            const unsigned long long n_tr = (unsigned long long)__popcll(__ballot(tr)), n_on = (unsigned long long)__popcll(__ballot(mode != 2));
+            if (__ffsll((long long)__ballot(true)) - 1 == lane) { atomicAdd(&cx.stats[28], 1ull); atomicAdd(&cx.stats[29], n_tr); atomicAdd(&cx.stats[30], n_on); }
+        }
+#endif
         if (any_lane(tr))
         {
             Hit h; bool occ;

@@ -876,6 +876,9 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
 /* ------------------------------------------------------------------------------------------------------------ */
 /* walk_pool: the per-lane walk with WORK HAND-OVER between the lanes of the wave.                              */
 /* ------------------------------------------------------------------------------------------------------------ */
+#ifndef QR_LONG_MIN
+#define QR_LONG_MIN 1       /* rays on one long hierarchy from which on they walk per lane: even one (its walk is shared out by walk_pool; 4: +5 % frame time) */
+#endif
 #ifndef QR_INCOH_MIN
 #define QR_INCOH_MIN 3      /* lanes left when the leader's group is at most a third of them: walk per lane (measured 3 vs 12: -7 % frame time) */
 #endif
@@ -1185,7 +1188,7 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         const int n_left = __popcll(pending), n_mine = __popcll(mine);
         const lm_t can_div = pending & LM((r.list & QR_LISTF_DIV) != 0);
         const bool incoherent = n_mine * 3 <= n_left && n_left >= QR_INCOH_MIN;
-        const bool long_list = !coherent && (head & QR_LISTF_LONG) != 0 && (head & QR_LISTF_DIV) != 0 && n_mine >= 4;
+        const bool long_list = !coherent && (head & QR_LISTF_LONG) != 0 && (head & QR_LISTF_DIV) != 0 && n_mine >= QR_LONG_MIN;
         if ((incoherent || long_list) && can_div != 0)
         {
             const lm_t go = incoherent ? can_div : mine;
