@@ -722,6 +722,14 @@ struct Builder
 int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks)
 {
+    static const bool timing = getenv("QR_COMPILE_TIMING") != nullptr;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto tick = [&](const char *what) {
+        if (!timing) return;
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "  compile %-10s %.3f ms\n", what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+        ts0 = t1;
+    };
     const int n_srf = (int)v.hdr->n_srf, n_mat = (int)v.hdr->n_mat, n_lgt = (int)v.hdr->n_lgt, n_tex = (int)v.hdr->n_texels;
     const char *cm = getenv("QR_CULL");                 /* 0 off, 1 planes, 2 planes + open quadrics, 3 all */
     const int cull_mode = cm ? atoi(cm) : 3;
@@ -787,11 +795,13 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         memcpy(b.at<qr_light>(b.o_lgt), v.lgt, (size_t)n_lgt * sizeof(qr_light));
         memcpy(b.at<uint32_t>(b.o_tex), v.texels, (size_t)n_tex * 4);
 
+        tick("setup");
         /* tile lists */
         std::vector<uint32_t> tile_off(T.size());
         for (size_t i = 0; i < T.size(); i++) tile_off[i] = b.compile_list(T[i]);
         memcpy(b.at<uint32_t>(o_til), tile_off.data(), tile_off.size() * 4);
 
+        tick("tiles");
         /* per-surface records (filled after the lists they point to exist) */
         for (int i = 0; i < n_srf; i++)
         {
@@ -890,6 +900,7 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
                 }
             hv_ent.insert(hv_ent.end(), lt_ent.begin(), lt_ent.end());
         }
+        tick("schedule");
         if (out.order.size() != n_sched * 2) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
         out.block_first.clear(); out.block_row.clear();
         if (sched_blocks > 1)
@@ -936,7 +947,10 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         out.has_grids = b.n_grids != 0;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
-    return qr_program_verify(out, err);
+    tick("finish");
+    const int vrc = qr_program_verify(out, err);
+    tick("verify");
+    return vrc;
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
