@@ -187,3 +187,26 @@ def test_gpu_synth_10k_objects_match_oracle(qr, oracle, seed):
     _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
     _, c = scn.render_count()
     assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}
+
+
+@pytest.mark.gpu
+def test_gpu_synth_multi_target_launch_matches_whole_frame(qr):
+    """The multi-target launch of the kernel instance with the per-lane walks (qr_render_multi_kernel<.., true>): three
+    row blocks of the 2000-object scene (walk_pool, shadow grids) and a block of an engine scene in ONE launch equal
+    the whole-frame renders -- what a rank of a sharded step does with a scene of this kind."""
+    import torch
+    import gzip
+    a = qr.Scene(qr.build_lists(_synth().make_scene(shadow_lists=False, **MID)), rebin_tiles=True)
+    with open(os.path.join(ROOT, "tests", "golden", "demo01_160.qrs.gz"), "rb") as f:
+        b = qr.Scene(gzip.decompress(f.read()))
+    whole_a = a.render(); whole_b = b.render(); torch.cuda.synchronize()
+    ha, hb = a.height, b.height
+    cuts = [0, 56, 64, ha]
+    fa = [torch.full_like(whole_a, 0x55) for _ in range(3)]
+    fb = torch.full_like(whole_b, 0x55)
+    qr.MultiRender([(a, fa[i], cuts[i], cuts[i + 1]) for i in range(3)] + [(b, fb, 8, hb - 8)])()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert bool((fa[i][cuts[i]:cuts[i + 1]] == whole_a[cuts[i]:cuts[i + 1]]).all())
+        assert bool((torch.cat([fa[i][:cuts[i]], fa[i][cuts[i + 1]:]]) == 0x55).all())
+    assert bool((fb[8:hb - 8] == whole_b[8:hb - 8]).all())
