@@ -540,7 +540,12 @@ void qr_render_multi_kernel(DevTargets tg, const uint32_t *__restrict__ order16,
     lp.row_begin = t.row_begin; lp.row_end = t.row_end;
     lp.index = 0; lp.thnum = 1;
     lp.group_first = t.row_begin / 8; lp.group_stride = 1;
-    lp.stats = nullptr; lp.dbg = 0;
+#ifdef QR_STATS
+    lp.stats = counters + 4;            /* instrumented builds count into the first scene's counter block */
+#else
+    lp.stats = nullptr;
+#endif
+    lp.dbg = 0;
     render_wave<false, DIVK>(lp, sched.x, sched.y, gw, t.frame, nullptr, counters);
 }
 
