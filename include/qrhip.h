@@ -135,7 +135,7 @@ typedef struct qr_program_info
     uint32_t n_sched;           /* wave-schedule entries (= waves of a whole-frame launch)    */
     uint32_t n_grids;           /* shadow lists by hit position built for large planes        */
     uint32_t n_grid_lists;      /* lists in them                                              */
-    uint32_t reserved[1];
+    uint32_t n_dda;             /* uniform grids built over long lists                        */
 } qr_program_info;
 int qr_program_stats(const void *blob, uint64_t size, qr_program_info *info);
 

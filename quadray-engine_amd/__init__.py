@@ -43,7 +43,7 @@ class SceneInfo(ctypes.Structure):
 class ProgramInfo(ctypes.Structure):
     _fields_ = [("bytes", ctypes.c_uint64), ("n_lists", ctypes.c_uint32), ("n_cells", ctypes.c_uint32),
                 ("n_dropped", ctypes.c_uint32), ("n_clip_cells", ctypes.c_uint32), ("n_sched", ctypes.c_uint32),
-                ("n_grids", ctypes.c_uint32), ("n_grid_lists", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 1)]
+                ("n_grids", ctypes.c_uint32), ("n_grid_lists", ctypes.c_uint32), ("n_dda", ctypes.c_uint32)]
 
 
 class RayCounts(ctypes.Structure):

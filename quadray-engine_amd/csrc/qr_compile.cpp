@@ -303,6 +303,8 @@ struct Builder
     std::vector<qr_elem> *Egrow = nullptr;  /* the same vector when the compiler may append filtered chains (shadow grids) */
     std::vector<int> light_user;            /* light list head -> the one surface that uses it, -2 several, -1 none */
     int grid_min = 256;                     /* shadow lists with at least this many surfaces get a grid       */
+    int dda_min = 0;                        /* lists with at least this many bounded members get a CDda (0: none) */
+    uint32_t n_dda = 0;
     uint32_t n_grids = 0, n_grid_lists = 0;
     const std::vector<BSphere> &bs;
     const int cull_mode;
@@ -501,7 +503,22 @@ struct Builder
         /* slot index of every cell: a bounding-volume cell takes two slots (its extension carries the volume) */
         for (int i = 0; i < n; i++) { emit_idx[i] = ne; if (ch[i].emit) { ne += (ch[i].op & QR_OPT_BV) ? 2 : 1; n_emitted++; } }
         emit_idx[n] = ne;
-        const uint32_t off = alloc((size_t)(ne + 1) * sizeof(CCell), 32);
+        /* uniform grid (CDda) for long world-space lists without clipper programs: decided before the cells are placed,
+         * the record sits in the 64 bytes in front of the program */
+        bool want_dda = false;
+        if (dda_min > 0 && !has_trnode)
+        {
+            int n_small = 0; bool ok = true;
+            for (int i = 0; i < n && ok; i++)
+            {
+                if (!ch[i].emit) continue;
+                if (ch[i].op & (QR_OPF_LOCAL | QR_OPF_CLIP)) ok = false;
+                if ((ch[i].op & QR_OPT_SOLVER) && bs[ch[i].si].r < 1e17f) n_small++;
+            }
+            want_dda = ok && n_small >= dda_min;
+        }
+        const uint32_t base = alloc((size_t)(ne + 1) * sizeof(CCell) + (want_dda ? sizeof(CDda) : 0), 64);
+        const uint32_t off = base + (want_dda ? (uint32_t)sizeof(CDda) : 0u);
         list_off[head] = off;
         for (int i = 0; i < n; i++)
         {
@@ -570,9 +587,98 @@ struct Builder
         for (int i = 0; i < n; i++)
             if (ch[i].emit && ((ch[i].op & QR_OPT_TRNODE) || (ch[i].op & QR_OPF_LOCAL))) world = false;
         if (world) lf |= QR_LISTF_WORLD;
+        if (want_dda && world && (lf & QR_LISTF_DIV)) { build_dda(base, off, n); lf |= QR_LISTF_DDA; any_long = true; }
         list_off[head] = off | lf;
         list_heavy[head] = heavy;
         return off | lf;
+    }
+
+    /*
+     * CDda of the list just emitted at `off` (ch / emit_idx still describe it): bins the members' bounding spheres.
+     */
+    void build_dda(uint32_t rec_off, uint32_t off, int n)
+    {
+        /* members: emitted solver cells; small ones span the grid */
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        std::vector<int> mem;
+        std::vector<float> rad;
+        for (int i = 0; i < n; i++)
+            if (ch[i].emit && (ch[i].op & QR_OPT_SOLVER)) { mem.push_back(i); if (bs[ch[i].si].r < 1e17f) rad.push_back(bs[ch[i].si].r); }
+        std::vector<float> sorted = rad;
+        std::sort(sorted.begin(), sorted.end());
+        const double r_big = 4.0 * (double)sorted[sorted.size() / 2] + 1e-3;        /* larger than 4 median radii: tested up front */
+        int n_small = 0;
+        for (int i : mem)
+        {
+            const BSphere &b = bs[ch[i].si];
+            if (!(b.r < r_big)) continue;
+            n_small++;
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)b.c[k] - b.r); hi[k] = std::max(hi[k], (double)b.c[k] + b.r); }
+        }
+        CDda g;
+        memset(&g, 0, sizeof(g));
+        double ext[3], vol = 1.0;
+        for (int k = 0; k < 3; k++) { lo[k] -= 1e-3; hi[k] += 1e-3; ext[k] = hi[k] - lo[k]; vol *= ext[k]; }
+        const double c0 = __builtin_cbrt(vol / (2.0 * (n_small > 0 ? n_small : 1)));      /* about two cells per member */
+        int dim[3];
+        for (int k = 0; k < 3; k++)
+        {
+            int d = (int)(ext[k] / c0 + 0.5);
+            dim[k] = d < 1 ? 1 : (d > (int)QR_GRID_MAX ? (int)QR_GRID_MAX : d);
+            g.org[k] = (float)lo[k]; g.size[k] = (float)(ext[k] / dim[k]); g.inv[k] = (float)(dim[k] / ext[k]);
+        }
+        g.dims = (uint32_t)dim[0] | ((uint32_t)dim[1] << 8) | ((uint32_t)dim[2] << 16);
+        const size_t n_cells = (size_t)dim[0] * dim[1] * dim[2];
+        /* count, then fill (members in list order inside a cell) */
+        auto range = [&](const BSphere &b, int k, int &a0, int &a1) {
+            /* cells overlap: members are entered a thousandth of a cell beyond their sphere's box, so that a hit within
+             * rounding of a cell face is found from either side */
+            const double pad = 1e-3 * g.size[k] + 1e-4;
+            a0 = (int)__builtin_floor(((double)b.c[k] - b.r - pad - lo[k]) * dim[k] / ext[k]);
+            a1 = (int)__builtin_floor(((double)b.c[k] + b.r + pad - lo[k]) * dim[k] / ext[k]);
+            a0 = a0 < 0 ? 0 : a0; a1 = a1 >= dim[k] ? dim[k] - 1 : a1;
+        };
+        std::vector<uint32_t> cnt(n_cells + 1, 0);
+        std::vector<int> outl;
+        for (int i : mem)
+        {
+            const BSphere &b = bs[ch[i].si];
+            if (!(b.r < r_big)) { outl.push_back(i); continue; }
+            int x0, x1, y0, y1, z0, z1;
+            range(b, 0, x0, x1); range(b, 1, y0, y1); range(b, 2, z0, z1);
+            for (int z = z0; z <= z1; z++) for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++)
+                cnt[((size_t)z * dim[1] + y) * dim[0] + x + 1]++;
+        }
+        g.n_out = (uint32_t)outl.size();
+        cnt[0] = g.n_out;
+        for (size_t c = 1; c <= n_cells; c++) cnt[c] += cnt[c - 1];
+        const uint32_t n_refs = cnt[n_cells];
+        g.n_refs = n_refs;
+        std::vector<CCell> refs(n_refs);
+        auto ref_of = [&](int i) {
+            CCell c = *at<CCell>(off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell));
+            uint32_t pos = off + (uint32_t)emit_idx[i] * (uint32_t)sizeof(CCell);
+            memcpy(&c.r2x, &pos, 4);            /* the original cell: list order decides between equal depths */
+            return c;
+        };
+        for (size_t q = 0; q < outl.size(); q++) refs[q] = ref_of(outl[q]);
+        std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (int i : mem)
+        {
+            const BSphere &b = bs[ch[i].si];
+            if (!(b.r < r_big)) continue;
+            int x0, x1, y0, y1, z0, z1;
+            range(b, 0, x0, x1); range(b, 1, y0, y1); range(b, 2, z0, z1);
+            const CCell c = ref_of(i);
+            for (int z = z0; z <= z1; z++) for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++)
+                refs[fill[((size_t)z * dim[1] + y) * dim[0] + x]++] = c;
+        }
+        g.cells = alloc((n_cells + 1) * 4, 16);
+        memcpy(at<uint32_t>(g.cells), cnt.data(), (n_cells + 1) * 4);
+        g.refs = alloc((size_t)(n_refs + 2) * sizeof(CCell), 32);        /* + slack: the walk loads 32 bytes at its cursor */
+        if (n_refs) memcpy(at<CCell>(g.refs), refs.data(), (size_t)n_refs * sizeof(CCell));
+        *at<CDda>(rec_off) = g;
+        n_dda++;
     }
 
     /* ---- clipper programs ---- */
@@ -754,6 +860,10 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
             }
         if (want_grids) Eg = E;
         Builder b(v, want_grids ? Eg : E, bs, cull_mode, out.blob);
+        {
+            const char *de = getenv("QR_DDA");          /* 0 turns the uniform grids off */
+            b.dda_min = de ? atoi(de) : 512;
+        }
         if (want_grids)
         {
             b.Egrow = &Eg; b.grid_min = grid_min;
@@ -941,7 +1051,7 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         out.off_srf = b.o_srf; out.off_shade = b.o_shd; out.off_mat = b.o_mat; out.off_lgt = b.o_lgt; out.off_tex = b.o_tex; out.off_tiles = o_til;
         out.n_srf = (uint32_t)n_srf; out.n_mat = (uint32_t)n_mat; out.n_lgt = (uint32_t)n_lgt; out.n_tex = (uint32_t)n_tex; out.n_tiles = (uint32_t)T.size();
         out.off_lists = o_ord + (uint32_t)(n_sched * 8 + 16);
-        b.st.bytes = out.blob.size(); b.st.n_grids = b.n_grids; b.st.n_grid_lists = b.n_grid_lists;
+        b.st.bytes = out.blob.size(); b.st.n_grids = b.n_grids; b.st.n_grid_lists = b.n_grid_lists; b.st.n_dda = b.n_dda;
         out.stats = b.st;
         out.has_long_lists = b.any_long;
         out.has_grids = b.n_grids != 0;
@@ -973,12 +1083,12 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     /* a list program: cells inside the list area, END-terminated, array ends on cell boundaries inside the run */
     auto check_list = [&](uint32_t off) -> const char * {
         if (off == 0) return nullptr;
-        if (off & 24u) return "list offset carries unknown flag bits";
-        const bool world = (off & QR_LISTF_WORLD) != 0;
+        if (off & 8u) return "list offset carries unknown flag bits";
+        const bool world = (off & QR_LISTF_WORLD) != 0, dda = (off & QR_LISTF_DDA) != 0;
         off &= ~31u;
         if (off < p.off_lists || (size_t)off + 32 > limit) return "list offset out of range";
-        if (slot[off / 32] & 1) return ((slot[off / 32] & 4) != 0) == world ? nullptr : "list referenced with different flags";
-        slot[off / 32] |= world ? 5 : 1;
+        if (slot[off / 32] & 1) return (((slot[off / 32] & 4) != 0) == world && ((slot[off / 32] & 8) != 0) == dda) ? nullptr : "list referenced with different flags";
+        slot[off / 32] |= (world ? 5 : 1) | (dda ? 8 : 0);
         uint32_t o = off, end_cell = 0;
         for (;;)
         {
@@ -1008,6 +1118,32 @@ int qr_program_verify(const QrProgram &p, std::string &err)
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
             if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";
             o += (t == QR_OPT_BV) ? 64 : 32;
+        }
+        if (dda)
+        {
+            /* the uniform grid in front of the program: tables inside the image, every ref a solver cell of THIS list */
+            if (!world || off < p.off_lists + sizeof(CDda)) return "grid record in front of a list that cannot have one";
+            const CDda *g = (const CDda *)(b.data() + off - sizeof(CDda));
+            const uint32_t nx = g->dims & 255u, ny = (g->dims >> 8) & 255u, nz = (g->dims >> 16) & 255u;
+            if ((g->dims >> 24) || nx < 1 || ny < 1 || nz < 1 || nx > QR_GRID_MAX || ny > QR_GRID_MAX || nz > QR_GRID_MAX) return "grid dimensions";
+            const size_t nc = (size_t)nx * ny * nz;
+            if ((g->cells & 3) || g->cells < p.off_lists || (size_t)g->cells + (nc + 1) * 4 > limit) return "grid cell table";
+            if ((g->refs & 31) || g->refs < p.off_lists || (size_t)g->refs + ((size_t)g->n_refs + 2) * sizeof(CCell) > limit) return "grid refs";
+            const uint32_t *cs = (const uint32_t *)(b.data() + g->cells);
+            if (cs[0] != g->n_out || cs[nc] != g->n_refs) return "grid cell table ends";
+            for (size_t q = 0; q < nc; q++) if (cs[q] > cs[q + 1]) return "grid cell table not monotone";
+            for (int k = 0; k < 3; k++) if (!(g->size[k] > 0.0f) || !(g->inv[k] > 0.0f) || !(g->size[k] < 1e30f) || !(g->inv[k] < 1e30f)) return "grid cell size";
+            const CCell *rf = (const CCell *)(b.data() + g->refs);
+            for (uint32_t q = 0; q < g->n_refs; q++)
+            {
+                const uint32_t t = rf[q].op & QR_OPT_MASK;
+                if (t == 0 || (t & (t - 1)) != 0 || !(t & QR_OPT_SOLVER) || (rf[q].op & (QR_OPF_LOCAL | QR_OPF_CLIP))) return "grid ref opcode";
+                if (!in_arr(rf[q].srf, p.off_srf, p.n_srf, sizeof(DSurf)) || rf[q].srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf)) return "grid ref surface";
+                uint32_t pos; memcpy(&pos, &rf[q].r2x, 4);
+                if (pos < off || pos >= end_cell || (pos & 31) || !(slot[pos / 32] & 2)) return "grid ref position";
+                const CCell *oc = (const CCell *)(b.data() + pos);
+                if (oc->op != rf[q].op || oc->srf != rf[q].srf) return "grid ref is not a copy of its cell";
+            }
         }
         return nullptr;
     };
@@ -1110,7 +1246,7 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
     memset(info, 0, sizeof(*info));
     info->bytes = p.stats.bytes; info->n_lists = p.stats.n_lists; info->n_cells = p.stats.n_cells;
     info->n_dropped = p.stats.n_dropped; info->n_clip_cells = p.stats.n_clip_cells; info->n_sched = p.n_sched;
-    info->n_grids = p.stats.n_grids; info->n_grid_lists = p.stats.n_grid_lists;
+    info->n_grids = p.stats.n_grids; info->n_grid_lists = p.stats.n_grid_lists; info->n_dda = p.stats.n_dda;
     return QR_OK;
 }
 

@@ -502,7 +502,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     for (int i = 0; i < iters; i++)
     {
 #ifdef QR_WAVETIME
-        HIP_TRY(hipMemsetAsync(s->d_counters + 32, 0, (size_t)s->lp.n_blocks * QR_WT_SLOTS * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(s->d_counters + 64, 0, (size_t)s->lp.n_blocks * QR_WT_SLOTS * sizeof(unsigned long long), st));
 #endif
         HIP_TRY(hipEventRecord(s->ev0, st));
         HIP_TRY(launch<false>(s, frame_dev, nullptr, st));
@@ -519,7 +519,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     {
         /* per wave of the last launch: {start, first traverse done, end} in 100 MHz ticks, {hw_id | xcc << 32 | walks << 40} */
         std::vector<unsigned long long> w((size_t)s->lp.n_blocks * QR_WT_SLOTS);
-        HIP_TRY(hipMemcpy(w.data(), s->d_counters + 32, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(w.data(), s->d_counters + 64, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         FILE *f = fopen(path, "wb");
         if (f) { fwrite(w.data(), sizeof(unsigned long long), w.size(), f); fclose(f); }
     }

@@ -26,7 +26,7 @@ struct BSphere { float c[3]; float r; };    /* conservative world-space bounding
 
 #define QR_SCHED_PER_LANE 0xFFFFFFFEu       /* schedule entry: the footprint straddles tiles, look the list up per pixel */
 
-struct QrProgramStats { uint64_t bytes; uint32_t n_lists, n_cells, n_dropped, n_clip_cells, n_grids, n_grid_lists; };
+struct QrProgramStats { uint64_t bytes; uint32_t n_lists, n_cells, n_dropped, n_clip_cells, n_grids, n_grid_lists, n_dda; };
 
 struct QrProgram
 {

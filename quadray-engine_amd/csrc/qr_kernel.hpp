@@ -195,7 +195,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 {
 #ifdef QR_WAVETIME
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long wt_mid = 0; u32 wt_push = 0;
+    unsigned long long wt_mid = 0, wt_trav = 0, wt_shade = 0, wt_t0 = 0; u32 wt_push = 0;
 #endif
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
@@ -323,6 +323,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         if (any_lane(tr))
         {
             Hit h; bool occ;
+#ifdef QR_WAVETIME
+            wt_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
             /* coherent: every ray of this round is a primary ray (neighbouring pixels) */
             const bool coherent = !any_lane(tr && sp != 0);
             traverse<false, DIVK>(B, tr, coherent, ray, h, occ
@@ -333,6 +336,8 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 #ifdef QR_WAVETIME
             if (wt_mid == 0) wt_mid = __builtin_amdgcn_s_memrealtime();
             wt_push++;
+            wt_trav += __builtin_amdgcn_s_memrealtime() - wt_t0;
+            wt_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
             const bool got = tr && h.srf != 0 && !QR_KNOB(4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
@@ -341,6 +346,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 
             Shaded o;
             shade<COUNT, DIVK>(cx, got, coherent, ray, h, o, cnt);
+#ifdef QR_WAVETIME
+            wt_shade += __builtin_amdgcn_s_memrealtime() - wt_t0;
+#endif
 
             if (got)
             {
@@ -447,8 +455,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 #ifdef QR_WAVETIME
     if (!COUNT && __ffsll((long long)__ballot(true)) - 1 == lane)
     {
-        unsigned long long *o = counters + 32 + (size_t)gw * QR_WT_SLOTS;
+        unsigned long long *o = counters + 64 + (size_t)gw * QR_WT_SLOTS;
         o[0] = wt_start; o[1] = wt_mid; o[2] = __builtin_amdgcn_s_memrealtime();
+        o[4] = 0; o[5] = 0; o[6] = 0; o[7] = wt_push; o[8] = wt_trav; o[9] = wt_shade; o[10] = 0;
         o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))
              | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 32)
              | ((unsigned long long)wt_push << 40);

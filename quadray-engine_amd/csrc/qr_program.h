@@ -77,6 +77,8 @@ struct CBvExt
 #define QR_LISTF_DIV   1u       /* no cell has a clipper program: the per-lane walk may take this list      */
 #define QR_LISTF_LONG  2u       /* a long hierarchy (bounding-volume arrays, many cells): rays part ways on it */
 #define QR_LISTF_WORLD 4u       /* every cell reads the world-space ray: no trnode cell, no QR_OPF_CACHED / QR_OPF_OWN cell */
+#define QR_LISTF_DDA   16u      /* a CDda record sits in the 64 bytes in front of the list program: nearest-hit rays that are
+                                 * not coherent may walk the uniform grid instead of the list (walk_dda)                 */
 #define QR_LISTF_GRID  8u       /* only in CLight::shadow: the offset is that of a CGrid, the shadow list depends on where the
                                  * surface was hit                                                                        */
 #define QR_LIST_OFF(x) ((x) & ~31u)
@@ -97,6 +99,24 @@ struct CGrid                    /* 32 B, 32-byte aligned */
     float    inv_a, inv_b;      /* cells per unit                                                                         */
 };
 #define QR_GRID_MAX 64u
+
+/*
+ * Uniform grid over the members of a long world-space list (ours).  A ray through a sparse cloud of thousands of small
+ * objects enters 60 fat bounding spheres of the scene's hierarchy and tests 250 cells to find the two objects it comes
+ * near; a grid of about one object per cell hands it those after ~35 cell steps.  The list program stays (packet walks
+ * of coherent rays, shadow rays); the grid holds COPIES of the members' cells, 32 bytes each with the r2x slot replaced
+ * by the byte offset of the original cell -- the position in list order that decides between equal depths
+ * (tracer.cpp:1626: strict compare, first in the list wins).  refs [0, n_out) are the members too large for the grid
+ * (or unbounded); they are tested first.  Bounding-volume elements of the list are not consulted: they only skip work
+ * (tracer.cpp:3955-4054) and hold their members with a margin far above the rounding of their own test.
+ */
+struct CDda                     /* 64 B, immediately in front of the list program's first cell */
+{
+    float    org[3];  uint32_t dims;    /* low corner; nx | ny << 8 | nz << 16, 1..QR_GRID_MAX each                       */
+    float    inv[3];  uint32_t cells;   /* cells per unit; byte offset of nx*ny*nz + 1 ref indices (cell i: [c[i], c[i+1])) */
+    float    size[3]; uint32_t refs;    /* units per cell; byte offset of the refs (CCell copies)                          */
+    uint32_t n_out;   uint32_t n_refs;  uint32_t pad[2];
+};
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
 

@@ -1158,6 +1158,174 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
 #endif
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* walk_dda: nearest hit through the uniform grid of a long world-space list (CDda, qr_program.h)               */
+/* ------------------------------------------------------------------------------------------------------------ */
+#ifndef QR_DDA
+#define QR_DDA 1
+#endif
+
+/* bit pattern of the next float above a positive finite t (equal depths: an earlier cell of the list still wins) */
+__device__ __forceinline__ float next_up(float t) { return u2f(f2u(t) + 1u); }
+
+/*
+ * Every lane walks ITS ray through the grid of ITS list: first the members too large for the grid (refs [0, n_out)),
+ * then cell by cell along the ray (3D-DDA), testing the cell's refs -- copies of the members' list cells -- with the
+ * conservative sphere test and, batched over the wave like walk_div's SOLVE, the solver + clip of the reference.
+ * The walk of a ray ends when its depth bound lies in front of the face through which it would leave the current
+ * cell.  Hits of equal depth: the reference keeps the first in list order (strict compare, tracer.cpp:1626); here
+ * members are met in grid order, so a candidate whose original cell lies in front of the best hit's is tested against
+ * the next float above the bound.  Same results as the list walk as long as the list's bounding volumes hold their
+ * members (they only skip work); tests/test_synth.py compares against the oracle, which walks the list.
+ */
+__device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit &h
+#ifdef QR_STATS
+                                         , unsigned long long *stats
+#endif
+                                         )
+{
+    WalkState w;
+    w.txyz = {0, 0, 0}; w.trijk = {0, 0, 0};
+    w.tbuf = r.tmax; w.resume = 0;
+    const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
+    const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    const float dde = dd * 1e-5f;
+    w.tbd = w.tbuf * dd;
+    u32 best_pos = 0xFFFFFFFFu;                 /* original cell of the best hit */
+    u32 last0 = 0, last1 = 0;                   /* surfaces solved last: a member spans several cells */
+
+    /* the record in front of the list program */
+    const u32 lo = active ? (r.list & ~31u) : 0u;
+    u32x4 g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0, g3 = g0;
+    if (active)
+    {
+        g0 = *(const QR_CONST u32x4 *)(B + (lo - 64u)); g1 = *(const QR_CONST u32x4 *)(B + (lo - 48u));
+        g2 = *(const QR_CONST u32x4 *)(B + (lo - 32u)); g3 = *(const QR_CONST u32x4 *)(B + (lo - 16u));
+    }
+    const u32 refs = g2.w, cells = g1.w;
+    const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
+    u32 rp = 0, rend = active ? g3.x : 0u;      /* ref cursor: the up-front members first */
+    u32 p_op = 0, p_srf = 0, p_pos = 0;
+
+    /* DDA state, set up once the up-front members are done */
+    float tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+    int ix = 0, iy = 0, iz = 0;
+    int phase = active ? 0 : 2;                 /* 0 up-front members, 1 grid cells, 2 done */
+#ifdef QR_STATS
+    unsigned long long st_iter = 0, st_lanes = 0, st_solve = 0, st_slanes = 0;
+#endif
+    for (;;)
+    {
+        const lm_t pend = LM(p_op != 0);
+        const lm_t adv = LM(phase != 2) & ~pend;
+        if ((adv | pend) == 0) break;
+        if (adv != 0 && __popcll(pend) < QR_DIV_BATCH)
+        {
+#ifdef QR_STATS
+            st_iter++; st_lanes += __popcll(adv);
+#endif
+            if (lane_of(adv))
+            {
+                if (rp < rend)
+                {
+                    /* ---- next ref of the current cell ---- */
+                    const u32 ro = refs + rp * 32u;
+                    const u32x4 a0 = *(const QR_CONST u32x4 *)(B + ro), a1 = *(const QR_CONST u32x4 *)(B + ro + 16);
+                    rp++;
+                    if (a0.y != last0 && a0.y != last1)
+                    {
+                        float b2, m, rhs;
+                        const float r2 = u2f(a0.z);
+                        if (!pool_cull(a0.y, a1, r2, r2 * 1.01f, false, r, dd, dde, dlen, w.tbd, b2, m, rhs))
+                        { p_op = a0.x; p_srf = a0.y; p_pos = a0.w; }
+                    }
+                }
+                else if (phase == 0)
+                {
+                    /* ---- enter the grid: clip the ray against its box, first cell, DDA increments ---- */
+                    phase = 1;
+                    const float ox = r.org.x - u2f(g0.x), oy = r.org.y - u2f(g0.y), oz = r.org.z - u2f(g0.z);
+                    const float ex = u2f(g2.x) * (float)nx, ey = u2f(g2.y) * (float)ny, ez = u2f(g2.z) * (float)nz;
+                    const float rx = __builtin_amdgcn_rcpf(r.dir.x), ry = __builtin_amdgcn_rcpf(r.dir.y), rz = __builtin_amdgcn_rcpf(r.dir.z);
+                    /* per axis the interval of t inside the slab (a ray parallel to it: everything or nothing) */
+                    float t_in = 0.0f, t_out = w.tbuf;
+                    bool miss = false;
+                    {
+                        const bool zx = r.dir.x == 0.0f, zy = r.dir.y == 0.0f, zz = r.dir.z == 0.0f;
+                        const float ax = -ox * rx, bx = (ex - ox) * rx, ay = -oy * ry, by = (ey - oy) * ry, az = -oz * rz, bz = (ez - oz) * rz;
+                        if (zx) miss = miss || ox < 0.0f || ox > ex; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ax, bx)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ax, bx)); }
+                        if (zy) miss = miss || oy < 0.0f || oy > ey; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ay, by)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ay, by)); }
+                        if (zz) miss = miss || oz < 0.0f || oz > ez; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(az, bz)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(az, bz)); }
+                    }
+                    if (miss || !(t_in <= t_out)) phase = 2;
+                    else
+                    {
+                        const float px = ox + r.dir.x * t_in, py = oy + r.dir.y * t_in, pz = oz + r.dir.z * t_in;
+                        ix = cvt_floor(px * u2f(g1.x)); iy = cvt_floor(py * u2f(g1.y)); iz = cvt_floor(pz * u2f(g1.z));
+                        ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix); iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy); iz = iz < 0 ? 0 : (iz >= nz ? nz - 1 : iz);
+                        const float inf = __builtin_inff();
+                        tdx = r.dir.x == 0.0f ? inf : u2f(g2.x) * __builtin_fabsf(rx);
+                        tdy = r.dir.y == 0.0f ? inf : u2f(g2.y) * __builtin_fabsf(ry);
+                        tdz = r.dir.z == 0.0f ? inf : u2f(g2.z) * __builtin_fabsf(rz);
+                        tmx = r.dir.x == 0.0f ? inf : ((float)(ix + (r.dir.x > 0.0f ? 1 : 0)) * u2f(g2.x) - ox) * rx;
+                        tmy = r.dir.y == 0.0f ? inf : ((float)(iy + (r.dir.y > 0.0f ? 1 : 0)) * u2f(g2.y) - oy) * ry;
+                        tmz = r.dir.z == 0.0f ? inf : ((float)(iz + (r.dir.z > 0.0f ? 1 : 0)) * u2f(g2.z) - oz) * rz;
+                        const u32 ci = cells + (u32)((iz * ny + iy) * nx + ix) * 4u;
+                        rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+                    }
+                }
+                else
+                {
+                    /* ---- leave the cell through its nearest face, unless the hit lies in front of it ---- */
+                    const float t_exit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+                    if (w.tbuf < t_exit) phase = 2;
+                    else
+                    {
+                        if (tmx <= tmy && tmx <= tmz) { ix += r.dir.x > 0.0f ? 1 : -1; tmx += tdx; }
+                        else if (tmy <= tmz)          { iy += r.dir.y > 0.0f ? 1 : -1; tmy += tdy; }
+                        else                          { iz += r.dir.z > 0.0f ? 1 : -1; tmz += tdz; }
+                        if ((unsigned)ix >= (unsigned)nx || (unsigned)iy >= (unsigned)ny || (unsigned)iz >= (unsigned)nz) phase = 2;
+                        else
+                        {
+                            const u32 ci = cells + (u32)((iz * ny + iy) * nx + ix) * 4u;
+                            rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+                        }
+                    }
+                }
+            }
+        }
+        else
+        {
+            /* ---- SOLVE ---- */
+#ifdef QR_STATS
+            st_solve++; st_slanes += __popcll(pend);
+#endif
+            if (lane_of(pend))
+            {
+                SurfS s;
+                ld_surf_lane(B, p_srf, s);
+                const float tb = w.tbuf;
+                const float tt = (p_pos < best_pos && best_pos != 0xFFFFFFFFu) ? next_up(tb) : tb;
+                w.tbuf = tt;
+                solve_cell<false, true, true>(B, p_op, p_srf, s, r, dd, w, h);
+                if (w.tbuf != tt) best_pos = p_pos;         /* accepted: solve_cell stored the new bound */
+                else w.tbuf = tb;
+                last1 = last0; last0 = p_srf;
+                p_op = 0;
+            }
+        }
+    }
+#ifdef QR_STATS
+    const unsigned long long st_start = (unsigned long long)__popcll(__ballot(active));
+    if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
+    {
+        atomicAdd(&stats[16], 1ull); atomicAdd(&stats[17], st_iter); atomicAdd(&stats[18], st_lanes);
+        atomicAdd(&stats[19], st_solve); atomicAdd(&stats[20], st_slanes); atomicAdd(&stats[21], st_start);
+    }
+#endif
+}
+
 /*
  * Wave-wide traversal: lanes with `active` walk their lists.  Lanes that share a list head are walked together
  * (wave-packet walk) as long as the wave is coherent; when the leading group is a small part of what is left
@@ -1193,6 +1361,18 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         {
             const lm_t go = incoherent ? can_div : mine;
             pending &= ~go;
+#if QR_DDA
+            /* nearest-hit rays on lists that carry a uniform grid */
+            if (!SHADOW && (go & LM((r.list & QR_LISTF_DDA) == 0)) == 0)
+            {
+                walk_dda(B, lane_of(go), r, h
+#ifdef QR_STATS
+                         , stats
+#endif
+                         );
+                continue;
+            }
+#endif
 #if QR_POOL
             /* hand-over needs lists without transform state (QR_LISTF_WORLD) */
             if ((go & LM((r.list & QR_LISTF_WORLD) == 0)) == 0)
