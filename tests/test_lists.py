@@ -63,6 +63,14 @@ def test_compiler_builds_shadow_grids_for_large_planes_only(qr):
     finally:
         del os.environ["QR_GRID"]
     assert off.n_grids == 0 and off.n_cells < info.n_cells
+    # uniform grids (CDda) over long world-space lists: the 2000-object scene's global list has one, QR_DDA=0 none
+    mid = qr.build_lists(_synth().make_scene(shadow_lists=False, n_objects=2000, width=64, height=36, depth=2, box=45.0))
+    assert qr.program_stats(mid).n_dda >= 1 and info.n_dda >= 1
+    os.environ["QR_DDA"] = "0"
+    try:
+        assert qr.program_stats(mid).n_dda == 0
+    finally:
+        del os.environ["QR_DDA"]
     os.environ["QR_GRID"] = "100000"                                         # threshold above the list's length
     try:
         assert qr.program_stats(built).n_grids == 0

@@ -121,14 +121,16 @@ def test_gpu_scene_without_objects(qr, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"QR_CULL": "0"}, {"QR_CULL": "1"}, {"QR_BIN_TILE": "8x8"},
-                                 {"QR_GRID": "0"}, {"QR_GRID": "64", "QR_CULL": "0"}])
+                                 {"QR_GRID": "0"}, {"QR_GRID": "64", "QR_CULL": "0"},
+                                 {"QR_DDA": "0"}, {"QR_DDA": "64", "QR_DDA_CELLS": "0.2"}, {"QR_DDA_CELLS": "16"}])
 def test_gpu_synth_build_variants_match_oracle(qr, oracle, env):
     """Upload-time variants of the compiled scene: no bounding-sphere cull cells, cull on planes only, 8x8 tiles
-    from the binning pass, without / with a lower threshold for the shadow lists by hit position: same pixels, hit ids
-    and ray counts as the oracle."""
+    from the binning pass, without / with a lower threshold for the shadow lists by hit position, without the uniform
+    grids of long lists (secondary rays walk the hierarchy with hand-over then) and with very coarse / very fine ones:
+    same pixels, hit ids and ray counts as the oracle."""
     import torch
     blob = _synth().make_scene(**MID)
-    if "QR_GRID" in env:
+    if "QR_GRID" in env or "QR_DDA" in env or "QR_DDA_CELLS" in env:
         blob = qr.build_lists(_synth().make_scene(shadow_lists=False, **MID))     # own light list per surface: grids apply
     os.environ.update(env)
     try:
