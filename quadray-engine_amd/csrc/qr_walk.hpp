@@ -1165,6 +1165,19 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
 #ifndef QR_DDA
 #define QR_DDA 1
 #endif
+#ifndef QR_DDA_KMAX
+#define QR_DDA_KMAX 64      /* segments per ray at most (4: +4 %, 16: +0.4 % frame time on the 10k scene) */
+#endif
+#ifndef QR_DDA_BATCH
+#define QR_DDA_BATCH 4      /* solve as soon as this many lanes hold a candidate: an early hit ends the march of every
+                             * segment behind it (16: +5 % frame time) */
+#endif
+#ifndef QR_DDA_SPLIT_MAXOWN
+#define QR_DDA_SPLIT_MAXOWN 32
+#endif
+#ifndef QR_DDA_SPLIT
+#define QR_DDA_SPLIT 1    /* rays of a sparse wave are cut into segments marched by idle lanes */
+#endif
 
 /* bit pattern of the next float above a positive finite t (equal depths: an earlier cell of the list still wins) */
 __device__ __forceinline__ float next_up(float t) { return u2f(f2u(t) + 1u); }
@@ -1178,6 +1191,13 @@ __device__ __forceinline__ float next_up(float t) { return u2f(f2u(t) + 1u); }
  * members are met in grid order, so a candidate whose original cell lies in front of the best hit's is tested against
  * the next float above the bound.  Same results as the list walk as long as the list's bounding volumes hold their
  * members (they only skip work); tests/test_synth.py compares against the oracle, which walks the list.
+ * Sparse waves: when at most half of the lanes have a ray for the grid, every ray's interval of t inside the grid is cut
+ * into 64 / rays segments and the idle lanes march the later ones (the ray from its owner's registers through
+ * ds_bpermute).  A segment ends at its far end, or as soon as the best hit known for the ray -- its own or, through
+ * LDS, another segment's -- lies in front of the face it would cross next.  Accepted hits meet in LDS as the minimum of
+ * (depth, original cell), as in walk_pool.  Marching a later segment is wasted when an earlier one finds a hit, but it
+ * occupies lanes that had nothing to do: 11 -> 30 of 64 lanes stepping, and with solver rounds from 4 candidates on
+ * an early hit ends the march of everything behind it.
  */
 __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit &h
 #ifdef QR_STATS
@@ -1185,137 +1205,220 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
 #endif
                                          )
 {
+    PoolLds &P = pool_lds();
+    const int lane = (int)(threadIdx.x & 63u);
+    Ray cr = r;                                 /* the ray this lane marches for (its own to begin with) */
+    int owner = lane;
     WalkState w;
     w.txyz = {0, 0, 0}; w.trijk = {0, 0, 0};
-    w.tbuf = r.tmax; w.resume = 0;
-    const float dd = r.dir.x * r.dir.x + r.dir.y * r.dir.y + r.dir.z * r.dir.z;
-    const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
-    const float dde = dd * 1e-5f;
+    w.tbuf = cr.tmax; w.resume = 0;
+    float dd = cr.dir.x * cr.dir.x + cr.dir.y * cr.dir.y + cr.dir.z * cr.dir.z;
+    float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+    float dde = dd * 1e-5f;
     w.tbd = w.tbuf * dd;
     u32 best_pos = 0xFFFFFFFFu;                 /* original cell of the best hit */
     u32 last0 = 0, last1 = 0;                   /* surfaces solved last: a member spans several cells */
+    Hit lh; lh.t = 0.0f; lh.srf = 0; lh.side = 0; lh.loc = {0, 0, 0};
 
     /* the record in front of the list program */
-    const u32 lo = active ? (r.list & ~31u) : 0u;
+    u32 lo = active ? (r.list & ~31u) : 0u;
     u32x4 g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0, g3 = g0;
     if (active)
     {
         g0 = *(const QR_CONST u32x4 *)(B + (lo - 64u)); g1 = *(const QR_CONST u32x4 *)(B + (lo - 48u));
         g2 = *(const QR_CONST u32x4 *)(B + (lo - 32u)); g3 = *(const QR_CONST u32x4 *)(B + (lo - 16u));
     }
-    const u32 refs = g2.w, cells = g1.w;
-    const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
     u32 rp = 0, rend = active ? g3.x : 0u;      /* ref cursor: the up-front members first */
     u32 p_op = 0, p_srf = 0, p_pos = 0;
-
-    /* DDA state, set up once the up-front members are done */
-    float tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0;
+    /* DDA state */
+    float tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0, t_end = 0;
     int ix = 0, iy = 0, iz = 0;
-    int phase = active ? 0 : 2;                 /* 0 up-front members, 1 grid cells, 2 done */
+    bool march = false;                         /* in the grid (pass 1) */
+    P.key[lane] = ((unsigned long long)f2u(r.tmax) << 32) | 0xFFFFFFFFull;
+    __syncthreads();
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0, st_solve = 0, st_slanes = 0;
 #endif
-    for (;;)
+#pragma nounroll
+    for (int pass = 0; pass < 2; pass++)
     {
-        const lm_t pend = LM(p_op != 0);
-        const lm_t adv = LM(phase != 2) & ~pend;
-        if ((adv | pend) == 0) break;
-        if (adv != 0 && __popcll(pend) < QR_DIV_BATCH)
+        if (pass == 1)
         {
-#ifdef QR_STATS
-            st_iter++; st_lanes += __popcll(adv);
-#endif
-            if (lane_of(adv))
+            /* ---- enter the grid: clip every ray against its box; the rays of a sparse wave are cut into 64 / rays
+             *      segments of t, the later ones marched by lanes that have nothing to do ---- */
+            float t_in = 0.0f, t_out = w.tbuf;
+            bool enter = active;
             {
-                if (rp < rend)
+                const float ox = cr.org.x - u2f(g0.x), oy = cr.org.y - u2f(g0.y), oz = cr.org.z - u2f(g0.z);
+                const float ex = u2f(g2.x) * (float)(g0.w & 255u), ey = u2f(g2.y) * (float)((g0.w >> 8) & 255u), ez = u2f(g2.z) * (float)((g0.w >> 16) & 255u);
+                const float rx = __builtin_amdgcn_rcpf(cr.dir.x), ry = __builtin_amdgcn_rcpf(cr.dir.y), rz = __builtin_amdgcn_rcpf(cr.dir.z);
+                const float ax = -ox * rx, bx = (ex - ox) * rx, ay = -oy * ry, by = (ey - oy) * ry, az = -oz * rz, bz = (ez - oz) * rz;
+                if (cr.dir.x == 0.0f) enter = enter && !(ox < 0.0f || ox > ex); else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ax, bx)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ax, bx)); }
+                if (cr.dir.y == 0.0f) enter = enter && !(oy < 0.0f || oy > ey); else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ay, by)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ay, by)); }
+                if (cr.dir.z == 0.0f) enter = enter && !(oz < 0.0f || oz > ez); else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(az, bz)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(az, bz)); }
+                enter = enter && (t_in <= t_out);
+            }
+            const lm_t owners = LM(enter);
+            const int n_own = __popcll(owners);
+            if (n_own == 0) break;
+            int K = 64 / n_own; K = K > QR_DDA_KMAX ? QR_DDA_KMAX : K;
+            if (n_own > QR_DDA_SPLIT_MAXOWN) K = 1;
+            int seg = 0;
+            march = enter;
+#if QR_DDA_SPLIT
+            if (K > 1)
+            {
+                const lm_t idle = ~owners;
+                const int rank_o = lanes_below(owners), rank_i = lanes_below(idle);
+                if (enter) P.give[rank_o] = u32x4{(u32)lane, 0u, 0u, 0u};
+                __syncthreads();
+                const bool help = !enter && rank_i < n_own * (K - 1);
+                const int src = help ? (int)P.give[rank_i % n_own].x : lane;
+                if (help) seg = 1 + rank_i / n_own;
+                /* the ray and what its owner knows so far, from the owner's registers (all lanes execute this) */
+                const float f_ox = __shfl(cr.org.x, src), f_oy = __shfl(cr.org.y, src), f_oz = __shfl(cr.org.z, src);
+                const float f_dx = __shfl(cr.dir.x, src), f_dy = __shfl(cr.dir.y, src), f_dz = __shfl(cr.dir.z, src);
+                const float f_tmn = __shfl(cr.tmin, src), f_tb = __shfl(w.tbuf, src);
+                const u32 f_osf = (u32)__shfl((int)cr.osrf, src); const int f_ofl = __shfl(cr.oflg, src);
+                const float f_px = __shfl(cr.ploc.x, src), f_py = __shfl(cr.ploc.y, src), f_pz = __shfl(cr.ploc.z, src);
+                const u32 f_lo = (u32)__shfl((int)lo, src), f_bp = (u32)__shfl((int)best_pos, src);
+                const float f_ti = __shfl(t_in, src), f_to = __shfl(t_out, src);
+                if (help)
                 {
-                    /* ---- next ref of the current cell ---- */
-                    const u32 ro = refs + rp * 32u;
-                    const u32x4 a0 = *(const QR_CONST u32x4 *)(B + ro), a1 = *(const QR_CONST u32x4 *)(B + ro + 16);
-                    rp++;
-                    if (a0.y != last0 && a0.y != last1)
-                    {
-                        float b2, m, rhs;
-                        const float r2 = u2f(a0.z);
-                        if (!pool_cull(a0.y, a1, r2, r2 * 1.01f, false, r, dd, dde, dlen, w.tbd, b2, m, rhs))
-                        { p_op = a0.x; p_srf = a0.y; p_pos = a0.w; }
-                    }
+                    owner = src; march = true;
+                    cr.org = {f_ox, f_oy, f_oz}; cr.dir = {f_dx, f_dy, f_dz}; cr.tmin = f_tmn; cr.tmax = f_tb;
+                    cr.osrf = f_osf; cr.oflg = f_ofl; cr.ploc = {f_px, f_py, f_pz};
+                    dd = f_dx * f_dx + f_dy * f_dy + f_dz * f_dz;
+                    dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+                    dde = dd * 1e-5f;
+                    w.tbuf = f_tb; w.tbd = f_tb * dd; w.resume = 0;
+                    best_pos = f_bp; lh.srf = 0; last0 = 0; last1 = 0;
+                    lo = f_lo; t_in = f_ti; t_out = f_to;
+                    g0 = *(const QR_CONST u32x4 *)(B + (lo - 64u)); g1 = *(const QR_CONST u32x4 *)(B + (lo - 48u));
+                    g2 = *(const QR_CONST u32x4 *)(B + (lo - 32u)); g3 = *(const QR_CONST u32x4 *)(B + (lo - 16u));
                 }
-                else if (phase == 0)
+                __syncthreads();
+            }
+            else K = 1;
+#else
+            K = 1;
+#endif
+            if (march)
+            {
+                /* this lane's segment of t, its first cell and the DDA increments */
+                const float dt = (t_out - t_in) * (1.0f / (float)K);
+                const float t0 = seg == 0 ? t_in : t_in + dt * (float)seg;
+                t_end = seg == K - 1 ? __builtin_inff() : t_in + dt * (float)(seg + 1);
+                const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
+                const float ox = cr.org.x - u2f(g0.x), oy = cr.org.y - u2f(g0.y), oz = cr.org.z - u2f(g0.z);
+                const float rx = __builtin_amdgcn_rcpf(cr.dir.x), ry = __builtin_amdgcn_rcpf(cr.dir.y), rz = __builtin_amdgcn_rcpf(cr.dir.z);
+                const float px = ox + cr.dir.x * t0, py = oy + cr.dir.y * t0, pz = oz + cr.dir.z * t0;
+                ix = cvt_floor(px * u2f(g1.x)); iy = cvt_floor(py * u2f(g1.y)); iz = cvt_floor(pz * u2f(g1.z));
+                ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix); iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy); iz = iz < 0 ? 0 : (iz >= nz ? nz - 1 : iz);
+                const float inf = __builtin_inff();
+                tdx = cr.dir.x == 0.0f ? inf : u2f(g2.x) * __builtin_fabsf(rx);
+                tdy = cr.dir.y == 0.0f ? inf : u2f(g2.y) * __builtin_fabsf(ry);
+                tdz = cr.dir.z == 0.0f ? inf : u2f(g2.z) * __builtin_fabsf(rz);
+                tmx = cr.dir.x == 0.0f ? inf : ((float)(ix + (cr.dir.x > 0.0f ? 1 : 0)) * u2f(g2.x) - ox) * rx;
+                tmy = cr.dir.y == 0.0f ? inf : ((float)(iy + (cr.dir.y > 0.0f ? 1 : 0)) * u2f(g2.y) - oy) * ry;
+                tmz = cr.dir.z == 0.0f ? inf : ((float)(iz + (cr.dir.z > 0.0f ? 1 : 0)) * u2f(g2.z) - oz) * rz;
+                const u32 ci = g1.w + (u32)((iz * ny + iy) * nx + ix) * 4u;
+                rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+            }
+        }
+        for (;;)
+        {
+            const lm_t pend = LM(p_op != 0);
+            const lm_t adv = (pass == 0 ? LM(rp < rend) : LM(march)) & ~pend;
+            if ((adv | pend) == 0) break;
+            if (adv != 0 && __popcll(pend) < QR_DDA_BATCH)
+            {
+#ifdef QR_STATS
+                st_iter++; st_lanes += __popcll(adv);
+#endif
+                if (lane_of(adv))
                 {
-                    /* ---- enter the grid: clip the ray against its box, first cell, DDA increments ---- */
-                    phase = 1;
-                    const float ox = r.org.x - u2f(g0.x), oy = r.org.y - u2f(g0.y), oz = r.org.z - u2f(g0.z);
-                    const float ex = u2f(g2.x) * (float)nx, ey = u2f(g2.y) * (float)ny, ez = u2f(g2.z) * (float)nz;
-                    const float rx = __builtin_amdgcn_rcpf(r.dir.x), ry = __builtin_amdgcn_rcpf(r.dir.y), rz = __builtin_amdgcn_rcpf(r.dir.z);
-                    /* per axis the interval of t inside the slab (a ray parallel to it: everything or nothing) */
-                    float t_in = 0.0f, t_out = w.tbuf;
-                    bool miss = false;
+                    if (rp < rend)
                     {
-                        const bool zx = r.dir.x == 0.0f, zy = r.dir.y == 0.0f, zz = r.dir.z == 0.0f;
-                        const float ax = -ox * rx, bx = (ex - ox) * rx, ay = -oy * ry, by = (ey - oy) * ry, az = -oz * rz, bz = (ez - oz) * rz;
-                        if (zx) miss = miss || ox < 0.0f || ox > ex; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ax, bx)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ax, bx)); }
-                        if (zy) miss = miss || oy < 0.0f || oy > ey; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(ay, by)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(ay, by)); }
-                        if (zz) miss = miss || oz < 0.0f || oz > ez; else { t_in = __builtin_fmaxf(t_in, __builtin_fminf(az, bz)); t_out = __builtin_fminf(t_out, __builtin_fmaxf(az, bz)); }
+                        /* ---- next ref of the current cell (or of the up-front members) ---- */
+                        const u32 ro = g2.w + rp * 32u;
+                        const u32x4 a0 = *(const QR_CONST u32x4 *)(B + ro), a1 = *(const QR_CONST u32x4 *)(B + ro + 16);
+                        rp++;
+                        if (a0.y != last0 && a0.y != last1)
+                        {
+                            float b2, m, rhs;
+                            const float r2 = u2f(a0.z);
+                            if (!pool_cull(a0.y, a1, r2, r2 * 1.01f, false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
+                            { p_op = a0.x; p_srf = a0.y; p_pos = a0.w; }
+                        }
                     }
-                    if (miss || !(t_in <= t_out)) phase = 2;
                     else
                     {
-                        const float px = ox + r.dir.x * t_in, py = oy + r.dir.y * t_in, pz = oz + r.dir.z * t_in;
-                        ix = cvt_floor(px * u2f(g1.x)); iy = cvt_floor(py * u2f(g1.y)); iz = cvt_floor(pz * u2f(g1.z));
-                        ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix); iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy); iz = iz < 0 ? 0 : (iz >= nz ? nz - 1 : iz);
-                        const float inf = __builtin_inff();
-                        tdx = r.dir.x == 0.0f ? inf : u2f(g2.x) * __builtin_fabsf(rx);
-                        tdy = r.dir.y == 0.0f ? inf : u2f(g2.y) * __builtin_fabsf(ry);
-                        tdz = r.dir.z == 0.0f ? inf : u2f(g2.z) * __builtin_fabsf(rz);
-                        tmx = r.dir.x == 0.0f ? inf : ((float)(ix + (r.dir.x > 0.0f ? 1 : 0)) * u2f(g2.x) - ox) * rx;
-                        tmy = r.dir.y == 0.0f ? inf : ((float)(iy + (r.dir.y > 0.0f ? 1 : 0)) * u2f(g2.y) - oy) * ry;
-                        tmz = r.dir.z == 0.0f ? inf : ((float)(iz + (r.dir.z > 0.0f ? 1 : 0)) * u2f(g2.z) - oz) * rz;
-                        const u32 ci = cells + (u32)((iz * ny + iy) * nx + ix) * 4u;
-                        rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
-                    }
-                }
-                else
-                {
-                    /* ---- leave the cell through its nearest face, unless the hit lies in front of it ---- */
-                    const float t_exit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-                    if (w.tbuf < t_exit) phase = 2;
-                    else
-                    {
-                        if (tmx <= tmy && tmx <= tmz) { ix += r.dir.x > 0.0f ? 1 : -1; tmx += tdx; }
-                        else if (tmy <= tmz)          { iy += r.dir.y > 0.0f ? 1 : -1; tmy += tdy; }
-                        else                          { iz += r.dir.z > 0.0f ? 1 : -1; tmz += tdz; }
-                        if ((unsigned)ix >= (unsigned)nx || (unsigned)iy >= (unsigned)ny || (unsigned)iz >= (unsigned)nz) phase = 2;
+                        /* ---- leave the cell through its nearest face, unless the best hit known for the ray -- this
+                         *      lane's or another segment's -- lies in front of that face, or the segment ends there ---- */
+                        const float t_exit = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+                        const float known = __builtin_fminf(w.tbuf, u2f(((const volatile u32 *)&P.key[owner])[1]));
+                        if (known < t_exit || t_exit >= t_end) march = false;
                         else
                         {
-                            const u32 ci = cells + (u32)((iz * ny + iy) * nx + ix) * 4u;
-                            rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+                            const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
+                            if (tmx <= tmy && tmx <= tmz) { ix += cr.dir.x > 0.0f ? 1 : -1; tmx += tdx; }
+                            else if (tmy <= tmz)          { iy += cr.dir.y > 0.0f ? 1 : -1; tmy += tdy; }
+                            else                          { iz += cr.dir.z > 0.0f ? 1 : -1; tmz += tdz; }
+                            if ((unsigned)ix >= (unsigned)nx || (unsigned)iy >= (unsigned)ny || (unsigned)iz >= (unsigned)nz) march = false;
+                            else
+                            {
+                                const u32 ci = g1.w + (u32)((iz * ny + iy) * nx + ix) * 4u;
+                                rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+                            }
                         }
                     }
                 }
             }
-        }
-        else
-        {
-            /* ---- SOLVE ---- */
-#ifdef QR_STATS
-            st_solve++; st_slanes += __popcll(pend);
-#endif
-            if (lane_of(pend))
+            else
             {
-                SurfS s;
-                ld_surf_lane(B, p_srf, s);
-                const float tb = w.tbuf;
-                const float tt = (p_pos < best_pos && best_pos != 0xFFFFFFFFu) ? next_up(tb) : tb;
-                w.tbuf = tt;
-                solve_cell<false, true, true>(B, p_op, p_srf, s, r, dd, w, h);
-                if (w.tbuf != tt) best_pos = p_pos;         /* accepted: solve_cell stored the new bound */
-                else w.tbuf = tb;
-                last1 = last0; last0 = p_srf;
-                p_op = 0;
+                /* ---- SOLVE ---- */
+#ifdef QR_STATS
+                st_solve++; st_slanes += __popcll(pend);
+#endif
+                bool accepted = false;
+                if (lane_of(pend))
+                {
+                    SurfS s;
+                    ld_surf_lane(B, p_srf, s);
+                    const float tb = w.tbuf;
+                    const float tt = (p_pos < best_pos && best_pos != 0xFFFFFFFFu) ? next_up(tb) : tb;
+                    w.tbuf = tt;
+                    solve_cell<false, true, true>(B, p_op, p_srf, s, cr, dd, w, lh);
+                    if (w.tbuf != tt) { best_pos = p_pos; accepted = true; }    /* solve_cell stored the new bound */
+                    else w.tbuf = tb;
+                    last1 = last0; last0 = p_srf;
+                    p_op = 0;
+                }
+                /* hits meet in LDS per ray: minimum of (depth, original cell) over all segments */
+                if (any_lane(accepted))
+                {
+                    const unsigned long long k = ((unsigned long long)f2u(lh.t) << 32) | (unsigned long long)best_pos;
+                    if (accepted) atomicMin(&P.key[owner], k);
+                    __syncthreads();
+                    if (accepted && P.key[owner] == k)
+                        P.hit[owner] = u32x4{lh.srf | (u32)lh.side, f2u(lh.loc.x), f2u(lh.loc.y), f2u(lh.loc.z)};
+                }
             }
         }
     }
+    __syncthreads();
+    if (active)
+    {
+        const unsigned long long k = P.key[lane];
+        if ((u32)k != 0xFFFFFFFFu)
+        {
+            const u32x4 q = P.hit[lane];
+            h.t = u2f((u32)(k >> 32)); h.srf = q.x & ~1u; h.side = (int)(q.x & 1u);
+            h.loc = {u2f(q.y), u2f(q.z), u2f(q.w)};
+        }
+    }
+    __syncthreads();
 #ifdef QR_STATS
     const unsigned long long st_start = (unsigned long long)__popcll(__ballot(active));
     if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63))
