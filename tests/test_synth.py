@@ -212,3 +212,28 @@ def test_gpu_synth_multi_target_launch_matches_whole_frame(qr):
         assert bool((fa[i][cuts[i]:cuts[i + 1]] == whole_a[cuts[i]:cuts[i + 1]]).all())
         assert bool((torch.cat([fa[i][:cuts[i]], fa[i][cuts[i + 1]:]]) == 0x55).all())
     assert bool((fb[8:hb - 8] == whole_b[8:hb - 8]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,box", [(1, 700, 14.0), (2, 1500, 22.0), (3, 3000, 60.0), (4, 900, 9.0)])
+def test_gpu_random_synth_scenes_match_oracle(qr, oracle, seed, n, box):
+    """Other object clouds than BASELINE's: from very dense (overlapping objects: rays inside glass bodies, many equal
+    or near-equal depths where list order decides) to sparse, more recursion, with low thresholds so that every long
+    list gets a uniform grid and the ground plane its shadow grids: pixels, hit ids and ray counts as the oracle."""
+    import torch
+    kw = dict(n_objects=n, width=320, height=180, depth=6, box=box, seed=seed)
+    blob = qr.build_lists(_synth().make_scene(shadow_lists=False, **kw))
+    os.environ.update({"QR_DDA": "64", "QR_GRID": "64"})
+    try:
+        assert qr.program_stats(blob).n_dda >= 1
+        scn = qr.Scene(blob, rebin_tiles=True)
+    finally:
+        del os.environ["QR_DDA"], os.environ["QR_GRID"]
+    frame = scn.new_frame(); ids = torch.full_like(frame, -2)
+    scn.render(frame, ids=ids); torch.cuda.synchronize()
+    o_frame, o_ids, _ = oracle.render(blob, threads=16, want_ids=True)
+    assert int((frame.cpu().numpy().view(np.uint32) != o_frame).sum()) == 0
+    assert (ids.cpu().numpy() == o_ids).all()
+    _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
+    _, c = scn.render_count()
+    assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}
