@@ -68,7 +68,8 @@
 #define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
 #endif
 #ifndef QR_DIVK_WAVES
-#define QR_DIVK_WAVES 4           /* the instance with the per-lane walks: 128 VGPRs and ~70 spilled beat 168 and none (latency: -8 % frame time) */
+#define QR_DIVK_WAVES 3           /* the instance with the per-lane walks: 168 VGPRs, none spilled.  (With walk_pool alone 4 waves and 70
+                                   * spilled registers were 8 % faster; with the grid walk's state it is 93 spilled and 1 % slower.) */
 #endif
 
 typedef uint32_t u32;

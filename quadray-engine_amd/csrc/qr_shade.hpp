@@ -25,7 +25,7 @@ struct Frame
 };
 #define QR_LDS_LEVELS 2
 #ifndef QR_LDS_LEVELS_DIVK
-#define QR_LDS_LEVELS_DIVK 1    /* the instance with walk_pool keeps 2.5 KB of LDS for it: 16 waves per CU need <= 10 KB each */
+#define QR_LDS_LEVELS_DIVK 2    /* + 2.5 KB for walk_pool / walk_dda: 10.5 KB per wave, 12 waves per CU (3 per SIMD) fit */
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
