@@ -417,6 +417,20 @@ def main():
                                algorithmic_bytes_per_launch=alg_bytes)
         if counters is not None:
             roofline["counters"] = counters
+            # What actually bounds the kernel: instruction issue.  tools/ubench/valu_rate.hip measured 0.93 G
+            # wave-instructions/s per SIMD on gfx950 (VALU and SALU share the slot), 1024 SIMDs.  The instruction count is
+            # the committed counter value (not measured in this run), the time is this run's: achieved = issued per
+            # launch / kernel time; with several launches in flight the per-frame rate is the one that counts.
+            insts = sum(counters.get(k, 0.0) for k in ("insts_valu", "insts_salu", "insts_smem", "insts_vmem_rd", "insts_vmem_wr"))
+            if insts > 0:
+                peak = 0.93 * 1024
+                per_launch = insts / (avg_ms * 1e-3) / 1e9
+                per_frame = insts * args.steps / dt / 1e9       # one frame's worth of instructions per GPU and step
+                roofline["issue"] = dict(unit="G wave-instructions/s", peak=peak, wave_instructions_per_launch=insts,
+                                         achieved_isolated_launch=per_launch, frac_isolated_launch=per_launch / peak,
+                                         achieved_in_flight=per_frame, frac_in_flight=per_frame / peak,
+                                         source="profiles/r02_valu_issue_rate.txt (peak), profiles/counters.json (count), this run (time)",
+                                         measured_in_this_run=False)
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
