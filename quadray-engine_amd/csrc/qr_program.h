@@ -108,7 +108,8 @@ struct CGrid                    /* 32 B, 32-byte aligned */
  * by the byte offset of the original cell -- the position in list order that decides between equal depths
  * (tracer.cpp:1626: strict compare, first in the list wins).  refs [0, n_out) are the members too large for the grid
  * (or unbounded); they are tested first.  Bounding-volume elements of the list are not consulted: they only skip work
- * (tracer.cpp:3955-4054) and hold their members with a margin far above the rounding of their own test.
+ * (tracer.cpp:3955-4054) and hold their members with a margin far above the rounding of their own test: the engine
+ * derives an array's volume from its members' boxes (rt_Array::update_bounds, object.cpp:1830), synth.py does the same.
  */
 struct CDda                     /* 64 B, immediately in front of the list program's first cell */
 {
