@@ -18,6 +18,7 @@
  *                    only in the binary linked with the shim (qr_ref_shim)
  *   --animate MS     advance the scene time by MS per --bench frame (objects, lights and camera move, the
  *                    engine rebuilds its lists: nothing can be reused from the previous frame)
+ *   --pt N           path-tracer mode: render N frames, the output is their running mean
  *   --bench N        wall-clock of N rt_Scene::render() calls (CPU baseline,
  *                    bench.py's cpu_baseline.kind == "reference")
  */
@@ -228,6 +229,7 @@ static void usage()
 
 int main(int argc, char **argv)
 {
+    int pt_frames = 0;
     const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL;
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
@@ -252,6 +254,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--gpu")) gpu = 1;
         else if (!strcmp(argv[i], "--animate") && i + 1 < argc) animate_ms = atol(argv[++i]);
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
         else { usage(); return 2; }
     }
     if (scene_name == NULL) { usage(); return 2; }
@@ -288,6 +291,13 @@ int main(int argc, char **argv)
         }
         for (int k = 0; k < camera; k++) sc->next_cam();
 
+        /* --pt N: path-tracer mode (rt_Scene::set_pton, engine.cpp:3729): N frames accumulate into the engine's colour
+         * planes, the frame shows their running mean */
+        if (pt_frames > 0)
+        {
+            sc->set_pton(1);
+            for (int k = 1; k < pt_frames; k++) sc->render(time_ms);
+        }
         sc->render(time_ms);
         rt_ui32 *frame = sc->get_frame();
         int row = sc->get_x_row();
