@@ -112,7 +112,9 @@ typedef struct qr_material
     float    c_rfl, c_trn, c_rfr, rfr_2, c_rcp, ext_2;
     float    clamp;         /* 255.0                                     */
     uint32_t cmask;         /* 255                                       */
-    int32_t  pad[11];
+    float    emis[3];       /* mat_COL_R/G/B (tracer.h:1065-1071): emission, read by the path tracer only;
+                             * the walker fills it for path-tracer snapshots (qr_frame.pt_on), 0 otherwise */
+    int32_t  pad[8];
 } qr_material;
 
 /* flattened rt_SIMD_LIGHT (tracer.h:765-811), 16 x 4 bytes */
@@ -152,7 +154,8 @@ typedef struct qr_frame
     int32_t  tile_w, tile_h, tls_row, tls_col;
     int32_t  clist;                 /* inf_LST head                      */
     int32_t  index, thnum;          /* row interleave of this call       */
-    int32_t  pad[8];
+    int32_t  pt_on;                 /* inf_PT_ON (tracer.h:216): captured in path-tracer mode */
+    int32_t  pad[7];
 } qr_frame;
 
 typedef struct qr_header

@@ -153,6 +153,17 @@ int qr_scene_get_info(const qr_device_scene *scn, qr_scene_info *info);
 int qr_scene_set_depth(qr_device_scene *scn, int depth);
 
 /*
+ * Path-tracer mode (the reference's RT_FEAT_PT, tracer.cpp:1112-1136, 1218-1285, 2339-2703, 3428-3466, 5176-5219;
+ * rt_Scene::set_pton, engine.cpp:3729).  on != 0 (re)starts the accumulation: per pixel sample one LCG24 state,
+ * seeded like rt_Scene::reset_pseed, and three colour planes on the device.  Every qr_render_async then adds ONE sample
+ * per pixel sample and writes the running mean as the frame.  Statistically equivalent to the reference, NOT bit-exact
+ * ("parity unpinned"): the reference's stream of random numbers depends on its eager shading order.
+ * Rendered by a packet-walk kernel instance of its own; ids / counting renders are refused in this mode; qr_render0
+ * (drop-in) refuses inf_PT_ON because the engine's planes live on the host.
+ */
+int qr_scene_set_pt(qr_device_scene *scn, int on);
+
+/*
  * Restrict rendering to framebuffer rows [row_begin, row_end) and, inside that,
  * to rows with (y % thnum) == index  -- the reference's thread interleave
  * (tracer.cpp:1144-1145, 5385-5386).  Default: whole frame, index 0, thnum 1.

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("QR_LIB") or os.path.join(_HERE, "libqrhip.so")   # QR
 # every symbol include/qrhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "qr_render0", "qr_capture_snapshot", "qr_flatten", "qr_free",
-    "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_snapshot_build_lists_c", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth",
+    "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_snapshot_build_lists_c", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth", "qr_scene_set_pt",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
     "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
@@ -90,6 +90,7 @@ def lib():
     L.qr_frame_hash.restype = cu64
     L.qr_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
     L.qr_scene_set_depth.argtypes = [vp, ci]
+    L.qr_scene_set_pt.argtypes = [vp, ci]
     L.qr_scene_set_rows.argtypes = [vp, ci, ci, ci, ci]
     L.qr_scene_set_tile_rows.argtypes = [vp, ci, ci]
     L.qr_render_async.argtypes = [vp, vp, vp]
@@ -178,6 +179,10 @@ class Scene:
     def set_depth(self, depth):
         _check(lib().qr_scene_set_depth(self._h, depth))
         self.info.depth = depth
+
+    def set_pt(self, on=True):
+        """Path-tracer mode: every render() then adds one sample per pixel sample; the frame is the running mean."""
+        _check(lib().qr_scene_set_pt(self._h, 1 if on else 0))
 
     def set_rows(self, row_begin, row_end, index=0, thnum=1):
         _check(lib().qr_scene_set_rows(self._h, row_begin, row_end, index, thnum))

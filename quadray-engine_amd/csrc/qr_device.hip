@@ -44,6 +44,10 @@ struct qr_device_scene
     size_t n_cells = 0;
     int32_t n_groups = 0;
     bool divk = false;          /* some list is a long hierarchy: launch the kernel instance with the per-lane walk */
+    /* path-tracer mode (qr_scene_set_pt): what the engine keeps per frame buffer, engine.cpp:2875-2893 */
+    bool pt_on = false;
+    uint32_t *d_seeds = nullptr; float *d_acc = nullptr;     /* frm_row * frm_h * samples each; d_acc holds r, g, b planes */
+    uint64_t pt_frames = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* the whole-frame wave schedule (host copy) and the schedules of the row selections rendered so far:
      * a launch restricted by qr_scene_set_rows / _set_tile_rows only starts the waves that own pixels */
@@ -214,6 +218,8 @@ extern "C" int qr_scene_destroy(qr_device_scene *s)
     for (auto &kv : s->sub) (void)hipFree(kv.second.d_order);
     (void)hipFree(s->d_counters);
     (void)hipFree(s->d_blob);
+    (void)hipFree(s->d_seeds);
+    (void)hipFree(s->d_acc);
     delete s;
     return QR_OK;
 }
@@ -236,6 +242,37 @@ extern "C" int qr_scene_set_depth(qr_device_scene *s, int depth)
     if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
     if (depth < 0 || depth > QR_MAX_DEPTH) return qr_fail(QR_ERR_ARG, "depth must be 0..10 (RT_STACK_DEPTH)");
     s->lp.depth = depth;
+    return QR_OK;
+}
+
+/*
+ * Path-tracer mode on / off.  Turning it on (re)starts the accumulation: the seed plane as rt_Scene::reset_pseed
+ * fills it (engine.cpp:3651-3685: a 48-bit LCG walks over the slots, each slot keeps the low 32 bits), colour planes 0.
+ */
+extern "C" int qr_scene_set_pt(qr_device_scene *s, int on)
+{
+    if (s == nullptr) return qr_fail(QR_ERR_ARG, "null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!on) { s->pt_on = false; return QR_OK; }
+    const size_t n = (size_t)s->fr.frm_row * s->fr.frm_h * ((size_t)1 << s->fr.fsaa);
+    if (s->fr.frm_row < s->fr.frm_w || n == 0 || n > ((size_t)1 << 30)) return qr_fail(QR_ERR_ARG, "bad frame stride for the sample planes");
+    if (s->d_seeds == nullptr)
+    {
+        HIP_TRY(hipMalloc((void **)&s->d_seeds, n * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s->d_acc, 3 * n * sizeof(float)));
+    }
+    std::vector<uint32_t> seeds(n);
+    unsigned long long seed = 1;
+    for (size_t k = 0; k < n; k++)
+    {
+        seed = (seed * 25214903917ull + 11ull) & 0x0000FFFFFFFFFFFFull;
+        seeds[k] = (uint32_t)seed;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s->d_seeds, seeds.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_acc, 0, 3 * n * sizeof(float)));
+    s->pt_frames = 0;
+    s->pt_on = true;
     return QR_OK;
 }
 
@@ -321,6 +358,18 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
                                     return (w == 3 || w == 4 || w == 5) ? w : QR_MIN_WAVES_PER_SIMD; }();
     uint32_t *f = (uint32_t *)frame_dev;
     (void)waves;
+    if (s->pt_on)
+    {
+        /* one more sample of every pixel sample: weights of the running mean, tracer.cpp:1112-1136 */
+        if (COUNT || ids_dev != nullptr) return hipErrorInvalidValue;
+        s->pt_frames++;
+        PtParams pt;
+        const size_t n = (size_t)s->fr.frm_row * s->fr.frm_h * ((size_t)1 << s->fr.fsaa);
+        pt.seeds = s->d_seeds; pt.acc_r = s->d_acc; pt.acc_g = s->d_acc + n; pt.acc_b = s->d_acc + 2 * n;
+        pt.pts_o = 1.0f / (float)s->pt_frames; pt.pts_u = 1.0f - pt.pts_o;
+        hipLaunchKernelGGL(qr_render_pt_kernel, grid, dim3(QR_BLOCK), 0, st, lp, pt, f, s->d_counters);
+        return hipGetLastError();
+    }
     if (s->divk) hipLaunchKernelGGL((qr_render_kernel<COUNT, QR_DIVK_WAVES, true>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
 #ifdef QR_WAVE_VARIANTS
     else if (!COUNT && waves == 3) hipLaunchKernelGGL((qr_render_kernel<false, 3, false>), grid, dim3(QR_BLOCK), 0, st, lp, f, ids_dev, s->d_counters);
@@ -731,6 +780,12 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     std::string err;
     int rc = qr_flatten_impl(s_inf, abi, c.blob, err);
     if (rc != QR_OK) return qr_fail(rc, err);
+    if (c.blob.size() >= sizeof(qr_header))
+    {
+        const qr_header *hh = (const qr_header *)c.blob.data();
+        if ((size_t)hh->off_frame + sizeof(qr_frame) <= c.blob.size() && ((const qr_frame *)(c.blob.data() + hh->off_frame))->pt_on)
+            return qr_fail(QR_ERR_UNSUP, "path-tracer mode (inf_PT_ON): the engine's colour and seed planes live on the host; use the snapshot API (qr_scene_set_pt)");
+    }
     const double t1 = now_ms();
 
     /* frame pointer and stride: inf_FRAME / inf_FRM_ROW, tracer.h:186-190 */

@@ -188,11 +188,18 @@ struct Hit
 
 __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 
+/*
+ * Path-tracer mode (RT_FEAT_PT; the third kernel instance only).  What the engine keeps per frame buffer
+ * (engine.cpp:2875-2893): one LCG state and three colour planes per pixel sample; pts_o = 1 / frames so far,
+ * pts_u = 1 - pts_o (tracer.cpp:1112-1136).
+ */
+struct PtParams { u32 *seeds; float *acc_r, *acc_g, *acc_b; float pts_o, pts_u; };
+
 /* one wave = one schedule entry: footprint `ord`, its tile-list program, rendered into `frame` */
-template <bool COUNT, bool DIVK>
+template <bool COUNT, bool DIVK, bool PT = false>
 __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, const u32 sched_head, const int gw,
                                             uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
-                                            unsigned long long *__restrict__ counters)
+                                            unsigned long long *__restrict__ counters, const PtParams *ptp = nullptr)
 {
 #ifdef QR_WAVETIME
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
@@ -253,6 +260,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     Counters cnt = {0, 0, 0, 0};
     const float t_inf = fr->fr.t_max;
 
+    u32 rng = 0;                                /* PT: this sample's LCG state */
     /* primary ray, tracer.cpp:1287-1322; sample offsets engine.cpp:3480-3550 */
     Ray ray;
     {
@@ -266,8 +274,23 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             const qr_frame *gf = (const qr_frame *)cx.G;
             ha = gf->hor_a[ai]; va = gf->ver_a[ai];
         }
-        float hs = (float)x + ha; hs = hs + 0.0f;
-        float vs = (float)y + va; vs = vs + 0.0f;
+        float hr = 0.0f, vr = 0.0f;
+        if constexpr (PT)
+        {
+            /* tent-filter jitter of the sample position, tracer.cpp:1218-1285 */
+            if (inside)
+            {
+                rng = ptp->seeds[((size_t)y * fr->fr.frm_row + x) * ns + k];     /* the engine's slot: row stride frm_row (tracer.cpp:1168-1176) */
+                float a = pt_random(rng); a = a + a;
+                hr = a < 1.0f ? __builtin_sqrtf(a) - 1.0f : 1.0f - __builtin_sqrtf(2.0f - a);
+                float b = pt_random(rng); b = b + b;
+                vr = b < 1.0f ? __builtin_sqrtf(b) - 1.0f : 1.0f - __builtin_sqrtf(2.0f - b);
+                hr = hr * 0.5f; vr = vr * 0.5f;
+                if (fsaa != 0) { hr = hr * 0.5f; vr = vr * 0.5f; }
+            }
+        }
+        float hs = (float)x + ha; hs = hs + hr;
+        float vs = (float)y + va; vs = vs + vr;
         float x1 = fr->fr.hor[0] * hs, x2 = fr->fr.hor[1] * hs, x3 = fr->fr.hor[2] * hs;
         float x4 = fr->fr.ver[0] * vs, x5 = fr->fr.ver[1] * vs, x6 = fr->fr.ver[2] * vs;
         x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
@@ -292,9 +315,10 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 
     /* recursion frames: levels 0..LDSL-1 in LDS ([level][quarter][lane]: a quarter of all lanes is contiguous,
      * 16-byte accesses at a 16-byte lane stride), deeper levels in scratch */
-    constexpr int LDSL = DIVK ? QR_LDS_LEVELS_DIVK : QR_LDS_LEVELS;
-    __shared__ f32x4 lds_frames[LDSL][4][64];
-    f32x4 deep[QR_MAX_DEPTH - LDSL][4];
+    constexpr int LDSL = PT ? 1 : (DIVK ? QR_LDS_LEVELS_DIVK : QR_LDS_LEVELS);
+    constexpr int FQ = PT ? 6 : 4;              /* quarters per frame: the path tracer also keeps its bounce (q4, q5) */
+    __shared__ f32x4 lds_frames[LDSL][FQ][64];
+    f32x4 deep[QR_MAX_DEPTH - LDSL][FQ];
     auto frame_put = [&](int level, int quarter, f32x4 v) {
         if (level < LDSL) lds_frames[level][quarter][lane] = v; else deep[level - LDSL][quarter] = v;
     };
@@ -346,7 +370,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (got && sp == 0) hit_id = (hsi << 1) | h.side;
 
             Shaded o;
-            shade<COUNT, DIVK>(cx, got, coherent, ray, h, o, cnt);
+            shade<COUNT, DIVK, PT>(cx, got, coherent, ray, h, o, cnt, &rng, depth - sp);
 #ifdef QR_WAVETIME
             wt_shade += __builtin_amdgcn_s_memrealtime() - wt_t0;
 #endif
@@ -354,12 +378,24 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             if (got)
             {
                 const bool can_spawn = (depth - sp) != 0;
-                const int meta = (hsi << 4) | (h.side << 3) | (o.want_rf ? 4 : 0);
+                /* PT: one more flag in front of the surface index: the node has a diffuse bounce to follow LAST (the
+                 * node's colour is linear in its children: rfl c_rfl + trn c_trn + x0 (bounce l_dff tex + emission)) */
+                const bool has_pt = PT && o.want_pt && can_spawn;
+                const int meta = PT ? ((hsi << 5) | (has_pt ? 16 : 0) | (h.side << 3) | (o.want_rf ? 4 : 0))
+                                    : ((hsi << 4) | (h.side << 3) | (o.want_rf ? 4 : 0));
+                if constexpr (PT)
+                {
+                    if (has_pt)
+                    {
+                        frame_put(sp, 4, f32x4{o.ptw.x * o.x0, o.ptw.y * o.x0, o.ptw.z * o.x0, 0.0f});
+                        frame_put(sp, 5, f32x4{o.pdir.x, o.pdir.y, o.pdir.z, 0.0f});
+                    }
+                }
                 if (o.want_tr && can_spawn)
                 {
                     frame_put(sp, 0, f32x4{o.col.x, o.col.y, o.col.z, __int_as_float(meta | 1)});
                     frame_put(sp, 1, f32x4{o.c_trn, o.c_rfl, o.x0, o.hit.x});
-                    if (o.want_rf)
+                    if (o.want_rf || has_pt)
                     {
                         /* only a node that also has a reflection child needs its direction and local hit later */
                         frame_put(sp, 2, f32x4{o.rdir.x, o.rdir.y, o.rdir.z, o.hit.y});
@@ -384,6 +420,11 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                         /* a reflection-only frame is read back for its colour and factor alone */
                         frame_put(sp, 0, f32x4{c.x, c.y, c.z, __int_as_float(meta | 2)});
                         frame_put(sp, 1, f32x4{o.c_trn, o.c_rfl, o.x0, o.hit.x});
+                        if (has_pt)
+                        {
+                            frame_put(sp, 2, f32x4{0.0f, 0.0f, 0.0f, o.hit.y});
+                            frame_put(sp, 3, f32x4{o.loc.x, o.loc.y, o.loc.z, o.hit.z});
+                        }
                         sp++;
                         ray.org = o.hit; ray.dir = o.rdir; ray.tmin = 0.0f; ray.tmax = t_inf;
                         ray.list = o.lst_rf; ray.osrf = h.srf; ray.oflg = h.side;
@@ -394,8 +435,21 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                     else
                     {
                         if (o.want_rf) { c.x = 0.0f + c.x; c.y = 0.0f + c.y; c.z = 0.0f + c.z; }
+                        if (has_pt)
+                        {
+                            /* no other child: the bounce at once */
+                            frame_put(sp, 0, f32x4{c.x, c.y, c.z, __int_as_float(meta | 3)});
+                            sp++;
+                            ray.org = o.hit; ray.dir = o.pdir; ray.tmin = 0.0f; ray.tmax = t_inf;
+                            ray.list = o.lst_pt; ray.osrf = h.srf; ray.oflg = h.side;
+                            ray.ploc = o.loc;
+                            mode = 0;
+                        }
+                        else
+                        {
                         ret = c;
                         mode = 1;
+                        }
                     }
                 }
             }
@@ -412,7 +466,30 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                 const f32x4 q0 = frame_get(sp - 1, 0), q1 = frame_get(sp - 1, 1);
                 const int fmeta = __float_as_int(q0.w);
                 const int phase = fmeta & 3;
-                if (phase == 1)
+                constexpr int MS = PT ? 5 : 4;              /* surface index sits above the flags */
+                /* PT: the node's other children are done, `c` is its colour without the bounce: follow the bounce now */
+                auto bounce = [&](V3 c) {
+                    const f32x4 q2 = frame_get(sp - 1, 2), q3 = frame_get(sp - 1, 3), q5 = frame_get(sp - 1, 5);
+                    frame_put(sp - 1, 0, f32x4{c.x, c.y, c.z, __int_as_float(fmeta | 3)});
+                    const int psi = fmeta >> MS, pside = (fmeta >> 3) & 1;
+                    ray.org = {q1.w, q2.w, q3.w};
+                    ray.dir = {q5.x, q5.y, q5.z};
+                    ray.tmin = 0.0f; ray.tmax = t_inf;
+                    ray.list = ((const DShade *)(cx.G + (cx.off_shade + (u32)psi * (u32)sizeof(DShade))))->lst[pside];
+                    ray.osrf = QR_OFF_SRF + ((u32)psi << 7); ray.oflg = pside;
+                    ray.ploc = {q3.x, q3.y, q3.z};
+                    mode = 0;
+                };
+                if (PT && phase == 3)
+                {
+                    /* PT_ret 2598-2620: the bounce's colour times l_dff tex (times x0, see above) */
+                    const f32x4 q4 = frame_get(sp - 1, 4);
+                    ret.x = q0.x + ret.x * q4.x;
+                    ret.y = q0.y + ret.y * q4.y;
+                    ret.z = q0.z + ret.z * q4.z;
+                    sp--;
+                }
+                else if (phase == 1)
                 {
                     /* TR_ret + TR_mix 3534-3598 */
                     V3 c;
@@ -425,7 +502,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                          * the same as for the refraction child) */
                         const f32x4 q2 = frame_get(sp - 1, 2), q3 = frame_get(sp - 1, 3);
                         frame_put(sp - 1, 0, f32x4{c.x, c.y, c.z, __int_as_float((fmeta & ~3) | 2)});
-                        const int psi = fmeta >> 4, pside = (fmeta >> 3) & 1;
+                        const int psi = fmeta >> MS, pside = (fmeta >> 3) & 1;
                         ray.org = {q1.w, q2.w, q3.w};
                         ray.dir = {q2.x, q2.y, q2.z};
                         ray.tmin = 0.0f; ray.tmax = t_inf;
@@ -435,6 +512,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                         mode = 0;
                         if (COUNT) cnt.reflect++;
                     }
+                    else if (PT && (fmeta & 16)) bounce(c);
                     else
                     {
                         ret = c;
@@ -444,10 +522,16 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                 else
                 {
                     /* RF_ret + RF_mix 3868-3908 */
-                    ret.x = ret.x * q1.y + q0.x;
-                    ret.y = ret.y * q1.y + q0.y;
-                    ret.z = ret.z * q1.y + q0.z;
-                    sp--;
+                    V3 c;
+                    c.x = ret.x * q1.y + q0.x;
+                    c.y = ret.y * q1.y + q0.y;
+                    c.z = ret.z * q1.y + q0.z;
+                    if (PT && (fmeta & 16)) bounce(c);
+                    else
+                    {
+                        ret = c;
+                        sp--;
+                    }
                 }
             }
         }
@@ -464,6 +548,20 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
              | ((unsigned long long)wt_push << 40);
     }
 #endif
+    if constexpr (PT)
+    {
+        /* 5176-5219: running mean of the samples in the colour planes; the frame shows the mean so far */
+        if (inside)
+        {
+            const size_t si = ((size_t)y * fr->fr.frm_row + x) * ns + k;
+            ptp->seeds[si] = rng;
+            const float ar = ret.x * ptp->pts_o + ptp->acc_r[si] * ptp->pts_u;
+            const float ag = ret.y * ptp->pts_o + ptp->acc_g[si] * ptp->pts_u;
+            const float ab = ret.z * ptp->pts_o + ptp->acc_b[si] * ptp->pts_u;
+            ptp->acc_r[si] = ar; ptp->acc_g[si] = ag; ptp->acc_b[si] = ab;
+            ret = {ar, ag, ab};
+        }
+    }
     /* XX_end 5161-5343: clamp, FSAA reduce, gamma, pack */
     float cr = clamp1(ret.x), cg = clamp1(ret.y), cb = clamp1(ret.z);
     if (fsaa >= 1)
@@ -519,6 +617,19 @@ void qr_render_kernel(LaunchP lp, uint32_t *__restrict__ frame, int32_t *__restr
     const u32x2 sched = ((const QR_CONST u32x2 *)lp.order)[gw];
 #pragma clang diagnostic pop
     render_wave<COUNT, DIVK>(lp, sched.x, sched.y, gw, frame, ids, counters);
+}
+
+/* path-tracer launch: one sample per pixel sample and call, accumulated in the planes of `pt` */
+__global__ __launch_bounds__(QR_BLOCK, 3)
+void qr_render_pt_kernel(LaunchP lp, PtParams pt, uint32_t *__restrict__ frame, unsigned long long *__restrict__ counters)
+{
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (QR_BLOCK / 64) + (int)(threadIdx.x >> 6));
+    if (gw >= lp.n_blocks) return;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const u32x2 sched = ((const QR_CONST u32x2 *)lp.order)[gw];
+#pragma clang diagnostic pop
+    render_wave<false, false, true>(lp, sched.x, sched.y, gw, frame, nullptr, counters, &pt);
 }
 
 /*

@@ -40,16 +40,52 @@ struct Shaded
     bool want_tr;           /* refraction child exists (M_TRN, not opaque)    */
     bool want_rf;           /* reflection pass applies (RF_ini reached)       */
     u32  lst_tr, lst_rf;    /* byte offsets of the children's list programs */
+    /* path tracer (PT instance only): the diffuse bounce, tracer.cpp:2339-2640 */
+    bool want_pt;           /* a bounce ray was sampled                       */
+    V3 pdir;                /* its direction                                  */
+    V3 ptw;                 /* l_dff * texture colour (after Russian roulette): weight of what it returns */
+    u32 lst_pt;             /* its list: the surface's own side, LST_P(SRF)   */
 };
+
+/*
+ * Path tracer: the reference's 24-bit LCG (GET_RANDOM, tracer.cpp:1013-1027; constants engine.cpp:866-874): the
+ * state advances, its upper 24 bits / 2^24 are the number.  One state per pixel sample, seeded like
+ * rt_Scene::reset_pseed (engine.cpp:3670-3685) and kept between frames.
+ */
+__device__ __forceinline__ float pt_random(u32 &state)
+{
+    state = state * 214013u + 2531011u;
+    return (float)(int32_t)((state >> 8) & 0xFFFFFFu) / 16777216.0f;
+}
+/* the reference's power series for sin / cos (tracer.cpp:1031-1057), used as they are: their error at +-pi is part of
+ * the distribution of the bounce directions */
+__device__ __forceinline__ float pt_sin(float x)
+{
+    const float t = x * x; float d = x, s = x * t;
+    d = d + s * -0.1666666666666666666666666666666666666666666f; s = s * t;
+    d = d + s * +0.0083333333333333333333333333333333333333333f; s = s * t;
+    d = d + s * -0.0001984126984126984126984126984126984126984f; s = s * t;
+    d = d + s * +0.0000027557319223985890652557319223985890652f;
+    return d;
+}
+__device__ __forceinline__ float pt_cos(float x)
+{
+    const float t = x * x; float d = 1.0f, s = t;
+    d = d + s * -0.5f; s = s * t;
+    d = d + s * +0.0416666666666666666666666666666666666666666f; s = s * t;
+    d = d + s * -0.0013888888888888888888888888888888888888888f; s = s * t;
+    d = d + s * +0.0000248015873015873015873015873015873015873f;
+    return d;
+}
 
 struct Counters { u32 primary, shadow, reflect, refract; };
 
 /* state of the enclosing recursion that only has to survive a shade() call */
 struct Outer { V3 ret; int hit_id, sp, mode; };
 
-template <bool COUNT, bool DIVK>
+template <bool COUNT, bool DIVK, bool PT = false>
 __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, const Ray &r, const Hit &h,
-                                      Shaded &o, Counters &cnt)
+                                      Shaded &o, Counters &cnt, u32 *rng = nullptr, int depth_left = 0)
 {
     /* per-lane (divergent) material data: vector loads at byte offsets from the blob base; everything
      * below is lane-private except the wave-wide shadow traversals in the light loop */
@@ -171,6 +207,56 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
             col.y = tex.y * fr->fr.amb[1];
             col.z = tex.z * fr->fr.amb[2];
             le = sd->lgt[side];
+        }
+    }
+
+    o.want_pt = false; o.pdir = {0, 0, 0}; o.ptw = {0, 0, 0}; o.lst_pt = 0;
+    if constexpr (PT)
+    {
+        /* path tracer, tracer.cpp:2339-2690: no light loop; the local colour is the material's emission, a diffuse
+         * surface samples one bounce over the cosine-weighted hemisphere */
+        le = 0;
+        col = {0, 0, 0};
+        if (act)
+        {
+            const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
+            V3 t3 = tex;
+            bool go = (props & QR_PROP_DIFFUSE) != 0;
+            if (go && depth_left <= QR_MAX_DEPTH - 5)
+            {
+                /* Russian roulette from the sixth level on: survive with the largest colour component */
+                float p = tex.x > tex.y ? tex.x : tex.y; p = p > tex.z ? p : tex.z;
+                const float u = pt_random(*rng);
+                go = u < p;
+                const float ip = 1.0f / p;
+                t3.x = tex.x * ip; t3.y = tex.y * ip; t3.z = tex.z * ip;
+            }
+            if (go)
+            {
+                /* orthonormal basis around the normal: u = normalize(n x ray), v = n x u */
+                V3 u, v;
+                u.x = nrm.y * r.dir.z - nrm.z * r.dir.y;
+                u.y = nrm.z * r.dir.x - nrm.x * r.dir.z;
+                u.z = nrm.x * r.dir.y - nrm.y * r.dir.x;
+                const float il = rsq(u.x * u.x + u.y * u.y + u.z * u.z);
+                u.x = u.x * il; u.y = u.y * il; u.z = u.z * il;
+                v.x = nrm.y * u.z - nrm.z * u.y;
+                v.y = nrm.z * u.x - nrm.x * u.z;
+                v.z = nrm.x * u.y - nrm.y * u.x;
+                const float r1 = pt_random(*rng);
+                const float s1 = __builtin_sqrtf(r1), c1 = __builtin_sqrtf(1.0f - r1);
+                const float r2 = pt_random(*rng);
+                const float pi = 3.14159265358979323846f;
+                const float phi = (r2 + r2) * pi - pi;
+                const float cp = pt_cos(phi) * s1, sp = pt_sin(phi) * s1;
+                o.pdir.x = nrm.x * c1 + u.x * cp + v.x * sp;
+                o.pdir.y = nrm.y * c1 + u.y * cp + v.y * sp;
+                o.pdir.z = nrm.z * c1 + u.z * cp + v.z * sp;
+                o.want_pt = true;
+                o.ptw.x = t3.x * mt->l_dff; o.ptw.y = t3.y * mt->l_dff; o.ptw.z = t3.z * mt->l_dff;
+                o.lst_pt = sd->lst[side];
+            }
+            col.x = mt->emis[0]; col.y = mt->emis[1]; col.z = mt->emis[2];
         }
     }
 
@@ -412,6 +498,20 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
             }
         }
 
+        bool rf_ok = true;
+        if constexpr (PT)
+        {
+            /* path tracer, 3428-3466: from the third level on a Fresnel surface follows ONE of the two children, the
+             * reflection with probability P = 0.25 + 0.5 c_rfl / (c_trn + c_rfl), weights divided by the probabilities */
+            if (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL) && depth_left <= QR_MAX_DEPTH - 2)
+            {
+                const float u = pt_random(*rng);
+                const float P = 0.25f + 0.5f * (c_rfl / (c_trn + c_rfl));
+                if (u < P) { o.want_tr = false; c_trn = 0.0f; c_rfl = c_rfl / P; }
+                else       { rf_ok = false; c_rfl = 0.0f; c_trn = c_trn / (1.0f - P); }
+            }
+        }
+
         /* TR_mix factor 3564-3573 */
         x0 = 1.0f - m_trn_c;
         x0 = x0 - m_rfl_c;
@@ -480,7 +580,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
                 x0 = x0 * m_rfl_c;
                 c_rfl = m_rfl_c + x0;
             }
-            o.want_rf = true;
+            o.want_rf = rf_ok;
             o.lst_rf = sd->lst[side];
         }
         o.c_trn = c_trn;

@@ -115,6 +115,7 @@ public:
 struct Walker
 {
     Abi a;
+    bool pt = false;            /* inf_PT_ON: materials carry their emission */
     std::vector<qr_surface>  srf;
     std::vector<qr_material> mat;
     std::vector<qr_light>    lgt;
@@ -208,6 +209,7 @@ struct Walker
         o.ext_2 = rd_f32(m, q * 0x13);
         o.clamp = rd_f32(m, q * 0x14);
         o.cmask = rd_u32(m, q * 0x15);
+        if (pt) { o.emis[0] = rd_f32(m, q * 0x17); o.emis[1] = rd_f32(m, q * 0x18); o.emis[2] = rd_f32(m, q * 0x19); }   /* mat_COL_R/G/B */
         if (o.xmask > 0xFFFF || o.ymask > 0xFFFF)
         {
             err = "material texture dimensions out of range";
@@ -459,7 +461,9 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     uint64_t p_tiles = rd_ptr(a, inf, slot(15));
     int32_t  pt_on   = (int32_t)rd_cell(a, inf, slot(19));
 
-    if (pt_on != 0) { err = "path-tracer mode (inf_PT_ON) is outside the accelerated path"; return QR_ERR_UNSUP; }
+    /* path-tracer mode: a snapshot can be captured (emission included); rendering through qr_render0 stays refused
+     * there, because the engine's colour and seed planes live on the host */
+    w.pt = pt_on != 0;
     if (p_ctx == 0 || p_cam == 0) { err = "s_inf->ctx / cam is NULL"; return QR_ERR_ARG; }
     if (frm_w <= 0 || frm_h <= 0 || frm_w > 65536 || frm_h > 65536) { err = "bad frame size"; return QR_ERR_ARG; }
     if (tile_w <= 0 || tile_h <= 0 || tls_row <= 0 || p_tiles == 0) { err = "bad tile parameters"; return QR_ERR_ARG; }
@@ -497,6 +501,7 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     f.tile_w = tile_w; f.tile_h = tile_h; f.tls_row = tls_row;
     f.tls_col = (frm_h + tile_h - 1) / tile_h;
     f.index = index; f.thnum = thnum;
+    f.pt_on = pt_on != 0 ? 1 : 0;
 
     const bool ph = getenv("QR_VERBOSE") && atoi(getenv("QR_VERBOSE")) >= 2;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

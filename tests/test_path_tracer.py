@@ -1,0 +1,111 @@
+"""Path-tracer mode (the reference's RT_FEAT_PT).
+
+PARITY UNPINNED.  The reference shades eagerly: every hit that passes the depth test while a list is walked is shaded
+at once, and in path-tracer mode that shading draws random numbers, so its stream of numbers depends on an order the
+deferred-shading backend does not have.  The backend uses the same generator, the same per-sample seeds
+(rt_Scene::reset_pseed), the same sampling formulas (tent-filter jitter, cosine hemisphere with the reference's power
+series, Russian roulette, Fresnel split) and the same running-mean accumulation, so its frames have the reference's
+DISTRIBUTION: these tests compare statistics of N accumulated frames with frames of the reference itself
+(tests/golden/pt/, made by tests/golden/make_pt_golden.py from oracle/_ref with the smallpt Cornell box, test18).
+The oracle has no path tracer: it is not involved here.
+"""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PT = os.path.join(ROOT, "tests", "golden", "pt")
+
+
+def _blob(name):
+    return gzip.decompress(open(os.path.join(PT, name + ".qrs.gz"), "rb").read())
+
+
+def _ref(name, w, h):
+    return np.frombuffer(gzip.decompress(open(os.path.join(PT, name + ".raw.gz"), "rb").read()), dtype=np.uint32).reshape(h, w)
+
+
+def _rgb(a):
+    return np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.float64)
+
+
+def _blocks(a, b=8):
+    h, w, _ = a.shape
+    return a.reshape(h // b, b, w // b, b, 3).mean((1, 3))
+
+
+def test_pt_snapshot_carries_the_flag_and_the_emission():
+    """The walker captures path-tracer snapshots (qr_frame.pt_on, qr_material.emis = mat_COL_R/G/B); ordinary snapshots
+    keep zeros there, so every older fixture is unchanged."""
+    b = _blob("test18_160_pt")
+    hdr = struct.unpack_from("<32I", b, 0)
+    n_mat, off_frame, off_mat = hdr[5], hdr[10], hdr[12]
+    fr = np.frombuffer(b, dtype=np.int32, count=49, offset=off_frame)
+    assert fr[41] == 1                                        # qr_frame.pt_on
+    m = np.frombuffer(b, dtype=np.float32, count=n_mat * 32, offset=off_mat).reshape(n_mat, 32)
+    emis = m[:, 21:24]
+    assert (emis == 12.0).all(axis=1).sum() >= 1              # smallpt's light: emission (12, 12, 12)
+    assert (emis == 0.0).all(axis=1).sum() >= n_mat - 2
+    plain = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "test18_160.qrs.gz"), "rb").read())
+    h2 = struct.unpack_from("<32I", plain, 0)
+    m2 = np.frombuffer(plain, dtype=np.float32, count=h2[5] * 32, offset=h2[12]).reshape(h2[5], 32)
+    assert (m2[:, 21:24] == 0.0).all()
+    assert np.frombuffer(plain, dtype=np.int32, count=49, offset=h2[10])[41] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("snap,ref,n,mean_tol,block_tol", [
+    ("test18_160_pt", "test18_160_pt_n64", 64, 1.0, 8.0),
+    ("test18_160_pt", "test18_160_pt_n512", 512, 0.6, 3.0),
+    ("test18_160_gf_aa4_pt", "test18_160_gf_aa4_pt_n128", 128, 0.8, 3.0),
+])
+def test_gpu_path_tracer_has_the_references_distribution(qr, snap, ref, n, mean_tol, block_tol):
+    """N accumulated frames against N accumulated frames of the reference: channel means of the whole frame and the
+    means of 8x8 pixel blocks.  Measured on MI355X: channel means within 0.2 of 255, block means 5.1 / 1.8 / 1.7 apart
+    on average (two independent estimates of the same image: the distance shrinks with sqrt(N))."""
+    import torch
+    scn = qr.Scene(_blob(snap))
+    want = _rgb(_ref(ref, scn.width, scn.height))
+    plain = _rgb(scn.render().cpu().numpy().view(np.uint32))         # ray-traced frame of the same snapshot
+    scn.set_pt(True)
+    f = scn.new_frame()
+    for _ in range(n):
+        scn.render(f)
+    torch.cuda.synchronize()
+    got = _rgb(f.cpu().numpy().view(np.uint32))
+    assert np.abs(got.mean((0, 1)) - want.mean((0, 1))).max() < mean_tol
+    assert np.abs(_blocks(got) - _blocks(want)).mean() < block_tol
+    # the statistic can tell images apart: the ray-traced frame of the same scene is far away from the reference's
+    assert np.abs(plain.mean((0, 1)) - want.mean((0, 1))).max() > 20.0
+    assert np.abs(_blocks(plain) - _blocks(want)).mean() > 4 * block_tol
+
+
+@pytest.mark.gpu
+def test_gpu_path_tracer_is_deterministic_and_restartable(qr, oracle):
+    """Same seeds, same frames: two accumulations of 16 frames are bit-identical; set_pt(True) restarts the mean;
+    set_pt(False) gives the ray-traced frame again, which is the oracle's (emission and the flag change nothing there)."""
+    import torch
+    blob = _blob("test18_160_pt")
+    scn = qr.Scene(blob)
+    runs = []
+    for _ in range(2):
+        scn.set_pt(True)
+        f = scn.new_frame()
+        for _ in range(16):
+            scn.render(f)
+        torch.cuda.synchronize()
+        runs.append(f.cpu().numpy().copy())
+    assert (runs[0] == runs[1]).all()
+    one = scn.new_frame()
+    scn.set_pt(True); scn.render(one); torch.cuda.synchronize()
+    assert (one.cpu().numpy() != runs[0]).any()                       # one sample is not the mean of sixteen
+    scn.set_pt(False)
+    rt = scn.render(); torch.cuda.synchronize()
+    o_frame, _, _ = oracle.render(blob, threads=4)
+    assert (rt.cpu().numpy().view(np.uint32) == o_frame).all()
+    with pytest.raises(qr.QrError):
+        scn.set_pt(True)
+        scn.render_count()                                            # counting renders are refused in this mode
