@@ -23,3 +23,11 @@ with tempfile.TemporaryDirectory() as tmp:
             with open(raw, "rb") as f, open(os.path.join(OUT, f"{name}_n{n}.raw.gz"), "wb") as g:
                 g.write(gzip.compress(f.read(), 9, mtime=0))
             print(name, n)
+    # first frame at recursion depth 0: bit-exact pin of seeding, generator, jitter, emission, accumulation
+    for name, opts in (("test18_160_pt_d0_n1", []), ("test18_160_aa4_pt_d0_n1", ["--fsaa", "4"])):
+        raw = os.path.join(tmp, "f.raw")
+        subprocess.run([REF, "--scene", "test18", "-w", "160", "-h", "120", "--depth", "0", "--pt", "1", "--out", raw] + opts,
+                       check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+        with open(raw, "rb") as f, open(os.path.join(OUT, name + ".raw.gz"), "wb") as g:
+            g.write(gzip.compress(f.read(), 9, mtime=0))
+        print(name)

@@ -8,6 +8,11 @@ series, Russian roulette, Fresnel split) and the same running-mean accumulation,
 DISTRIBUTION: these tests compare statistics of N accumulated frames with frames of the reference itself
 (tests/golden/pt/, made by tests/golden/make_pt_golden.py from oracle/_ref with the smallpt Cornell box, test18).
 The oracle has no path tracer: it is not involved here.
+
+What IS pinned bit-exactly: the first frame at recursion depth 0.  There the colour of a pixel is the emission of the
+surface its jittered primary ray meets, and the jitter uses the first two numbers of the sample's stream, before any
+shading: seeding, generator, jitter arithmetic, emission, accumulation and packing must reproduce the reference's frame
+pixel for pixel (test_gpu_path_tracer_first_frame_depth0_is_bit_exact).
 """
 import gzip
 import os
@@ -109,3 +114,26 @@ def test_gpu_path_tracer_is_deterministic_and_restartable(qr, oracle):
     with pytest.raises(qr.QrError):
         scn.set_pt(True)
         scn.render_count()                                            # counting renders are refused in this mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ref,fsaa", [("test18_160_pt_d0_n1", 0), ("test18_160_aa4_pt_d0_n1", 2)])
+def test_gpu_path_tracer_first_frame_depth0_is_bit_exact(qr, ref, fsaa):
+    """qr_ref --scene test18 --depth 0 --pt 1 [--fsaa 4]: the reference's first path-traced frame without recursion."""
+    import torch
+    b = bytearray(_blob("test18_160_pt"))
+    if fsaa:
+        # same scene with 4x FSAA: the engine's sample offsets (engine.cpp:3525-3546 pattern, as in the aa4 snapshot)
+        a = _blob("test18_160_gf_aa4_pt")
+        oa, ob = struct.unpack_from("<I", a, 40)[0], struct.unpack_from("<I", b, 40)[0]
+        fa = np.frombuffer(a, dtype=np.uint32, count=49, offset=oa)
+        fb = np.frombuffer(bytes(b), dtype=np.uint32, count=49, offset=ob).copy()
+        fb[10:18] = fa[10:18]; fb[30] = fa[30]                 # hor_a / ver_a, fsaa
+        b[ob:ob + 196] = fb.tobytes()
+    scn = qr.Scene(bytes(b))
+    scn.set_depth(0)
+    scn.set_pt(True)
+    f = scn.render(); torch.cuda.synchronize()
+    want = _ref(ref, scn.width, scn.height)
+    assert int((want != 0).sum()) > 100
+    assert int((f.cpu().numpy().view(np.uint32) != want).sum()) == 0
