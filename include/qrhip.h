@@ -29,7 +29,7 @@ typedef enum qr_status
     QR_OK            =  0,
     QR_ERR_ARG       = -1,  /* bad argument / malformed snapshot            */
     QR_ERR_ABI       = -2,  /* unsupported reference build configuration    */
-    QR_ERR_UNSUP     = -3,  /* feature outside the hot path (path tracer)   */
+    QR_ERR_UNSUP     = -3,  /* outside what this entry point does (e.g. inf_PT_ON through qr_render0, 8x FSAA) */
     QR_ERR_DEVICE    = -4,  /* no usable HIP device / HIP runtime error     */
     QR_ERR_IO        = -5,
     QR_ERR_NOMEM     = -6
