@@ -414,6 +414,7 @@ extern "C" int qr_render_multi_async(int n, qr_device_scene *const *scenes, void
     for (int i = 0; i < n; i++)
     {
         if (scenes[i] == nullptr || frames_dev[i] == nullptr) return qr_fail(QR_ERR_ARG, "null scene or frame");
+        if (scenes[i]->pt_on) return qr_fail(QR_ERR_UNSUP, "a scene in path-tracer mode cannot be part of a multi-target launch");
         if (scenes[i]->device != scenes[0]->device) return qr_fail(QR_ERR_ARG, "scenes live on different devices");
         if (row_begin[i] < 0 || row_end[i] > scenes[i]->fr.frm_h || row_begin[i] > row_end[i]) return qr_fail(QR_ERR_ARG, "bad row range");
     }

@@ -111,9 +111,11 @@ def test_gpu_path_tracer_is_deterministic_and_restartable(qr, oracle):
     rt = scn.render(); torch.cuda.synchronize()
     o_frame, _, _ = oracle.render(blob, threads=4)
     assert (rt.cpu().numpy().view(np.uint32) == o_frame).all()
+    scn.set_pt(True)
     with pytest.raises(qr.QrError):
-        scn.set_pt(True)
         scn.render_count()                                            # counting renders are refused in this mode
+    with pytest.raises(qr.QrError):
+        qr.MultiRender([(scn, scn.new_frame(), 0, scn.height)])()    # and so are multi-target launches
 
 
 @pytest.mark.gpu
