@@ -295,6 +295,11 @@ int main(int argc, char **argv)
          * planes, the frame shows their running mean */
         if (pt_frames > 0)
         {
+            if (getenv("QR_REF_PT_WARM"))
+            {
+                /* experiment: one path-traced frame, then restart the accumulation (seeds and planes are reset) */
+                sc->set_pton(1); sc->render(time_ms); sc->set_pton(0); sc->render(time_ms);   /* the ray-traced frame resets the sample count, tracer.cpp:1128-1132 */
+            }
             sc->set_pton(1);
             for (int k = 1; k < pt_frames; k++) sc->render(time_ms);
         }

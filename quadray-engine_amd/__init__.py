@@ -180,9 +180,10 @@ class Scene:
         _check(lib().qr_scene_set_depth(self._h, depth))
         self.info.depth = depth
 
-    def set_pt(self, on=True):
-        """Path-tracer mode: every render() then adds one sample per pixel sample; the frame is the running mean."""
-        _check(lib().qr_scene_set_pt(self._h, 1 if on else 0))
+    def set_pt(self, on=True, eager=False):
+        """Path-tracer mode: every render() then adds one sample per pixel sample; the frame is the running mean.
+        eager: shade in the reference's order (every hit that passes the depth test, at once): its random streams."""
+        _check(lib().qr_scene_set_pt(self._h, (2 if eager else 1) if on else 0))
 
     def set_rows(self, row_begin, row_end, index=0, thnum=1):
         _check(lib().qr_scene_set_rows(self._h, row_begin, row_end, index, thnum))

@@ -48,6 +48,7 @@ struct qr_device_scene
     bool pt_on = false;
     uint32_t *d_seeds = nullptr; float *d_acc = nullptr;     /* frm_row * frm_h * samples each; d_acc holds r, g, b planes */
     uint64_t pt_frames = 0;
+    int pt_eager = 0;           /* 1: the reference's shading order (qr_pt_eager.hpp): its random streams, slow; 3: self-test */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     /* the whole-frame wave schedule (host copy) and the schedules of the row selections rendered so far:
      * a launch restricted by qr_scene_set_rows / _set_tile_rows only starts the waves that own pixels */
@@ -273,6 +274,7 @@ extern "C" int qr_scene_set_pt(qr_device_scene *s, int on)
     HIP_TRY(hipMemset(s->d_acc, 0, 3 * n * sizeof(float)));
     s->pt_frames = 0;
     s->pt_on = true;
+    s->pt_eager = on == 2 ? 1 : (on == 3 ? 3 : 0);
     return QR_OK;
 }
 
@@ -367,6 +369,7 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
         const size_t n = (size_t)s->fr.frm_row * s->fr.frm_h * ((size_t)1 << s->fr.fsaa);
         pt.seeds = s->d_seeds; pt.acc_r = s->d_acc; pt.acc_g = s->d_acc + n; pt.acc_b = s->d_acc + 2 * n;
         pt.pts_o = 1.0f / (float)s->pt_frames; pt.pts_u = 1.0f - pt.pts_o;
+        pt.eager = s->pt_eager; pt.pad = 0;
         hipLaunchKernelGGL(qr_render_pt_kernel, grid, dim3(QR_BLOCK), 0, st, lp, pt, f, s->d_counters);
         return hipGetLastError();
     }

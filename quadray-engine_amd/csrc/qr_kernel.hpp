@@ -181,6 +181,7 @@ struct Hit
 
 #include "qr_walk.hpp"
 #include "qr_shade.hpp"
+#include "qr_pt_eager.hpp"
 
 /* ------------------------------------------------------------------------ */
 /* the kernel                                                                */
@@ -193,7 +194,7 @@ __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
  * (engine.cpp:2875-2893): one LCG state and three colour planes per pixel sample; pts_o = 1 / frames so far,
  * pts_u = 1 - pts_o (tracer.cpp:1112-1136).
  */
-struct PtParams { u32 *seeds; float *acc_r, *acc_g, *acc_b; float pts_o, pts_u; };
+struct PtParams { u32 *seeds; float *acc_r, *acc_g, *acc_b; float pts_o, pts_u; int eager, pad; };
 
 /* one wave = one schedule entry: footprint `ord`, its tile-list program, rendered into `frame` */
 template <bool COUNT, bool DIVK, bool PT = false>
@@ -278,7 +279,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         if constexpr (PT)
         {
             /* tent-filter jitter of the sample position, tracer.cpp:1218-1285 */
-            if (inside)
+            if (inside && ptp->eager != 3)
             {
                 rng = ptp->seeds[((size_t)y * fr->fr.frm_row + x) * ns + k];     /* the engine's slot: row stride frm_row (tracer.cpp:1168-1176) */
                 float a = pt_random(rng); a = a + a;
@@ -336,7 +337,17 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 
     if (COUNT && inside) cnt.primary++;
 
-    while (any_lane(mode != 2))
+    bool eager_done = false;
+    if constexpr (PT)
+    {
+        if (ptp->eager)
+        {
+            ret = pt_eager(cx, ray, inside, depth, t_inf, rng, ptp->eager == 3);
+            eager_done = true;
+        }
+    }
+
+    while (!eager_done && any_lane(mode != 2))
     {
         const bool tr = mode == 0;
 #ifdef QR_STATS

@@ -44,6 +44,7 @@ struct Shaded
     bool want_pt;           /* a bounce ray was sampled                       */
     V3 pdir;                /* its direction                                  */
     V3 ptw;                 /* l_dff * texture colour (after Russian roulette): weight of what it returns */
+    V3 ptex; float pldff;   /* the two factors apart (the eager path tracer multiplies in the reference's order) */
     u32 lst_pt;             /* its list: the surface's own side, LST_P(SRF)   */
 };
 
@@ -61,20 +62,22 @@ __device__ __forceinline__ float pt_random(u32 &state)
  * the distribution of the bounce directions */
 __device__ __forceinline__ float pt_sin(float x)
 {
+    /* fmaps3ld is a fused multiply-add on the reference's AVX2 / AVX-512 targets (vfmadd231ps,
+     * rtarch_x86_512x1v2.h:572-581, RT_SIMD_COMPAT_FMA 1): one rounding per term */
     const float t = x * x; float d = x, s = x * t;
-    d = d + s * -0.1666666666666666666666666666666666666666666f; s = s * t;
-    d = d + s * +0.0083333333333333333333333333333333333333333f; s = s * t;
-    d = d + s * -0.0001984126984126984126984126984126984126984f; s = s * t;
-    d = d + s * +0.0000027557319223985890652557319223985890652f;
+    d = __builtin_fmaf(s, -0.1666666666666666666666666666666666666666666f, d); s = s * t;
+    d = __builtin_fmaf(s, +0.0083333333333333333333333333333333333333333f, d); s = s * t;
+    d = __builtin_fmaf(s, -0.0001984126984126984126984126984126984126984f, d); s = s * t;
+    d = __builtin_fmaf(s, +0.0000027557319223985890652557319223985890652f, d);
     return d;
 }
 __device__ __forceinline__ float pt_cos(float x)
 {
     const float t = x * x; float d = 1.0f, s = t;
-    d = d + s * -0.5f; s = s * t;
-    d = d + s * +0.0416666666666666666666666666666666666666666f; s = s * t;
-    d = d + s * -0.0013888888888888888888888888888888888888888f; s = s * t;
-    d = d + s * +0.0000248015873015873015873015873015873015873f;
+    d = __builtin_fmaf(s, -0.5f, d); s = s * t;
+    d = __builtin_fmaf(s, +0.0416666666666666666666666666666666666666666f, d); s = s * t;
+    d = __builtin_fmaf(s, -0.0013888888888888888888888888888888888888888f, d); s = s * t;
+    d = __builtin_fmaf(s, +0.0000248015873015873015873015873015873015873f, d);
     return d;
 }
 
@@ -85,8 +88,11 @@ struct Outer { V3 ret; int hit_id, sp, mode; };
 
 template <bool COUNT, bool DIVK, bool PT = false>
 __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, const Ray &r, const Hit &h,
-                                      Shaded &o, Counters &cnt, u32 *rng = nullptr, int depth_left = 0)
+                                      Shaded &o, Counters &cnt, u32 *rng = nullptr, int depth_left = 0, int pt_stage = 0)
 {
+    /* pt_stage (PT only): 0 everything in one call (the statistical path tracer); 1 up to the bounce sampling; 2 only the
+     * transparency / reflection part -- the eager path tracer calls the two stages around the bounce's subtree, because
+     * the Fresnel split draws its number after that subtree has drawn its own (tracer.cpp: 2339-2703 before 3428-3466) */
     /* per-lane (divergent) material data: vector loads at byte offsets from the blob base; everything
      * below is lane-private except the wave-wide shadow traversals in the light loop */
     const BaseP B = cx.B;
@@ -210,7 +216,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         }
     }
 
-    o.want_pt = false; o.pdir = {0, 0, 0}; o.ptw = {0, 0, 0}; o.lst_pt = 0;
+    o.want_pt = false; o.pdir = {0, 0, 0}; o.ptw = {0, 0, 0}; o.lst_pt = 0; o.ptex = {0, 0, 0}; o.pldff = 0.0f;
     if constexpr (PT)
     {
         /* path tracer, tracer.cpp:2339-2690: no light loop; the local colour is the material's emission, a diffuse
@@ -221,7 +227,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         {
             const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
             V3 t3 = tex;
-            bool go = (props & QR_PROP_DIFFUSE) != 0;
+            bool go = (props & QR_PROP_DIFFUSE) != 0 && pt_stage != 2;
             if (go && depth_left <= QR_MAX_DEPTH - 5)
             {
                 /* Russian roulette from the sixth level on: survive with the largest colour component */
@@ -254,6 +260,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
                 o.pdir.z = nrm.z * c1 + u.z * cp + v.z * sp;
                 o.want_pt = true;
                 o.ptw.x = t3.x * mt->l_dff; o.ptw.y = t3.y * mt->l_dff; o.ptw.z = t3.z * mt->l_dff;
+                o.ptex = t3; o.pldff = mt->l_dff;
                 o.lst_pt = sd->lst[side];
             }
             col.x = mt->emis[0]; col.y = mt->emis[1]; col.z = mt->emis[2];
@@ -420,7 +427,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
     o.want_tr = false; o.want_rf = false;
     o.lst_tr = 0; o.lst_rf = 0;
 
-    if (act)
+    if (act && pt_stage != 1)
     {
         const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
         const float m_trn_c = mt->c_trn, m_rfl_c = mt->c_rfl;
