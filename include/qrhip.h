@@ -75,6 +75,14 @@ int qr_render0(const void *s_inf, const qr_abi_desc *abi);
  */
 int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, const char *path);
 
+/*
+ * Which snapshot index the last qr_capture_snapshot on this thread gave to one of the engine's records:
+ * kind 0 = rt_SIMD_SURFACE (tracer.h:821) -> qr_surface index, the value hit-id planes carry;
+ * kind 1 = rt_SIMD_LIGHT (tracer.h:765) -> qr_light index.  -1 when the record is not part of the snapshot.
+ * This is how a host maps the objects of its hierarchy (include/qr_hierarchy.h) to snapshot records.
+ */
+int qr_capture_index(int kind, const void *record);
+
 /* As above into a malloc'ed buffer the caller releases with qr_free. */
 int qr_flatten(const void *s_inf, const qr_abi_desc *abi, void **blob, uint64_t *size);
 void qr_free(void *blob);

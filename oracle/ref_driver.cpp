@@ -224,13 +224,96 @@ static void usage()
     fprintf(stderr,
         "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
         "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
-        "              [--out F.raw] [--snapshot F.qrs] [--bench N] [--camera K]\n");
+        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K]\n");
+}
+
+
+/*
+ * --tree F.json: the object hierarchy as the engine holds it after the frame at time T -- per object the inputs of
+ * the hierarchical update (parent, tag, rt_TRANSFORM3D after the animators ran, shape parameters) and its results
+ * (matrix, trnode, transform flags), plus the snapshot index (qr_capture_index) of the SIMD records each object owns.
+ * Fixture for include/qr_hierarchy.h (tests/test_hierarchy.py); floats are written as their 32 bits in hex.
+ * The engine keeps these members private; this TU is compiled with -fno-access-control (oracle/Makefile).
+ */
+extern "C" int qr_capture_index(int kind, const void *record) __attribute__((weak));   /* libqrhip: qr_ref_shim only */
+static int capture_index(int kind, const void *r) { return qr_capture_index ? qr_capture_index(kind, r) : -1; }
+
+static void put_f(FILE *f, const char *key, const rt_real *v, int n)
+{
+    fprintf(f, "\"%s\": [", key);
+    for (int i = 0; i < n; i++)
+    {
+        uint32_t u; float x = (float)v[i]; memcpy(&u, &x, 4);
+        fprintf(f, "%s\"%08x\"", i ? ", " : "", u);
+    }
+    fprintf(f, "]");
+}
+
+static void dump_node(FILE *f, rt_Object *o, int parent, std::vector<rt_Object *> &seen, bool &first)
+{
+    const int me = (int)seen.size();
+    seen.push_back(o);
+    fprintf(f, "%s\n  {\"parent\": %d, \"tag\": %d, \"anim\": %d, ", first ? "" : ",", parent, (int)o->tag, o->obj->f_anim != RT_NULL ? 1 : 0);
+    first = false;
+    put_f(f, "scl", o->trm->scl, 3); fprintf(f, ", ");
+    put_f(f, "rot", o->trm->rot, 3); fprintf(f, ", ");
+    put_f(f, "pos", o->trm->pos, 3); fprintf(f, ", ");
+    rt_real shape[3] = { 0, 0, 0 };
+    if (o->tag > RT_TAG_PLANE && o->tag < RT_TAG_SURFACE_MAX)
+    {
+        const rt_real *p = (const rt_real *)((rt_SURFACE *)o->obj->obj.pobj + 1);   /* parameters follow rt_SURFACE, format.h:496-727 */
+        const int n = (o->tag == RT_TAG_HYPERBOLOID || o->tag == RT_TAG_HYPERCYLINDER || o->tag == RT_TAG_HYPERPARABOLOID) ? 2 : 1;
+        for (int i = 0; i < n; i++) shape[i] = p[i];
+    }
+    put_f(f, "shape", shape, 3); fprintf(f, ", ");
+    put_f(f, "mtx", &o->mtx[0][0], 16); fprintf(f, ", ");
+    int trn = -1;
+    for (size_t i = 0; i < seen.size(); i++) if (seen[i] == o->trnode) trn = (int)i;
+    fprintf(f, "\"trnode\": %d, \"obj_has_trm\": %d, \"mtx_has_trm\": %d", trn, (int)o->obj_has_trm, (int)o->mtx_has_trm);
+    if (o->tag == RT_TAG_LIGHT)
+    {
+        fprintf(f, ", \"lgt\": %d", capture_index(1, ((rt_Light *)o)->s_lgt));
+    }
+    else if (o->tag == RT_TAG_CAMERA)
+    {
+        fprintf(f, ", "); put_f(f, "pov", &((rt_Camera *)o)->pov, 1);
+    }
+    else
+    {
+        fprintf(f, ", \"srf\": %d", capture_index(0, ((rt_Node *)o)->s_srf));
+    }
+    if (o->tag == RT_TAG_ARRAY)
+    {
+        rt_Array *a = (rt_Array *)o;
+        fprintf(f, ", \"inb\": %d, \"bvb\": %d}", capture_index(0, a->s_inb), capture_index(0, a->s_bvb));
+        for (int i = 0; i < a->obj_num; i++) dump_node(f, a->obj_arr[i], me, seen, first);
+    }
+    else
+    {
+        fprintf(f, "}");
+    }
+}
+
+static bool dump_tree(rt_Scene *sc, const char *scene, long time_ms, const char *path)
+{
+    FILE *f = fopen(path, "w");
+    if (f == NULL) { fprintf(stderr, "cannot open %s\n", path); return false; }
+    std::vector<rt_Object *> seen;
+    fprintf(f, "{\"scene\": \"%s\", \"time\": %ld, \"opts\": %d, \"x_res\": %d, \"y_res\": %d, \"nodes\": [", scene, time_ms,
+            (int)sc->opts, (int)sc->x_res, (int)sc->y_res);
+    bool first = true;
+    dump_node(f, sc->root, -1, seen, first);
+    int cam = -1;
+    for (size_t i = 0; i < seen.size(); i++) if (seen[i] == (rt_Object *)sc->cam) cam = (int)i;
+    fprintf(f, "\n], \"camera\": %d}\n", cam);
+    fclose(f);
+    return true;
 }
 
 int main(int argc, char **argv)
 {
     int pt_frames = 0;
-    const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL;
+    const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL, *tree_path = NULL;
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
     long time_ms = 0, animate_ms = 0;
@@ -255,6 +338,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--animate") && i + 1 < argc) animate_ms = atol(argv[++i]);
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
         else { usage(); return 2; }
     }
     if (scene_name == NULL) { usage(); return 2; }
@@ -413,6 +497,12 @@ int main(int argc, char **argv)
                 return 5;
             }
             printf("snapshot %s\n", snap_path);
+        }
+
+        if (tree_path != NULL)
+        {
+            if (!dump_tree(sc, scene_name, time_ms, tree_path)) return 3;
+            printf("tree %s\n", tree_path);
         }
 
         delete sc;

@@ -21,7 +21,9 @@ ABI_SYMBOLS = [
     "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_snapshot_build_lists_c", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth", "qr_scene_set_pt",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
-    "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name",
+    "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name", "qr_capture_index",
+    # include/qr_hierarchy.h
+    "qr_hierarchy_update", "qr_hierarchy_animate", "qr_hierarchy_apply", "qr_anim_spin", "qr_anim_swing",
 ]
 
 
@@ -99,6 +101,9 @@ def lib():
     L.qr_render_count.argtypes = [vp, vp, vp, ctypes.POINTER(RayCounts)]
     L.qr_render_host.argtypes = [vp, vp, ci]
     L.qr_render_timed.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.qr_hierarchy_update.argtypes = [vp, ci, ctypes.c_uint32, vp]
+    L.qr_hierarchy_animate.argtypes = [vp, ci, ctypes.c_int64, vp, vp, vp, ci]
+    L.qr_hierarchy_apply.argtypes = [vp, cu64, vp, vp, ci, ctypes.c_uint32, ci, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(cu64)]
     _lib = L
     return L
 
@@ -129,6 +134,81 @@ def build_lists(blob):
     out, n = ctypes.c_void_p(), ctypes.c_uint64()
     buf = ctypes.create_string_buffer(blob, len(blob))
     _check(lib().qr_snapshot_build_lists_c(buf, len(blob), ctypes.byref(out), ctypes.byref(n)))
+    try:
+        return ctypes.string_at(out, n.value)
+    finally:
+        lib().qr_free(out)
+
+
+# ---- object hierarchy (include/qr_hierarchy.h): numpy record arrays in the C layout of qr_node / qr_node_state ----
+
+def node_dtype():
+    import numpy as np
+    return np.dtype([("parent", "<i4"), ("tag", "<i4"), ("scl", "<f4", 3), ("rot", "<f4", 3), ("pos", "<f4", 3),
+                     ("shape", "<f4", 3), ("srf", "<i4"), ("inb", "<i4"), ("bvb", "<i4"), ("lgt", "<i4"), ("anim", "<i4"),
+                     ("pov", "<f4"), ("pad", "<i4", 2)])
+
+
+def node_state_dtype():
+    import numpy as np
+    return np.dtype([("mtx", "<f4", 16), ("map", "<i4", 4), ("sgn", "<i4", 4), ("scl", "<f4", 4), ("trnode", "<i4"),
+                     ("obj_has_trm", "<i4"), ("mtx_has_trm", "<i4"), ("pad", "<i4")])
+
+
+HIER_RESET_TILES = 1
+ANIM_SPIN, ANIM_SWING = "spin", "swing"
+
+
+def hierarchy_update(nodes, opts):
+    """Hierarchical transform update (qr_hierarchy_update): nodes (node_dtype array) -> node_state_dtype array."""
+    import numpy as np
+    nodes = np.ascontiguousarray(nodes, dtype=node_dtype())
+    out = np.zeros(len(nodes), dtype=node_state_dtype())
+    _check(lib().qr_hierarchy_update(nodes.ctypes.data_as(ctypes.c_void_p), len(nodes), opts, out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+class _AnimParams(ctypes.Structure):
+    _fields_ = [("axis", ctypes.c_int32), ("rate", ctypes.c_float), ("period", ctypes.c_float), ("pad", ctypes.c_int32)]
+
+
+def hierarchy_animate(nodes, time, node_time, animators):
+    """Run the animators (qr_hierarchy_animate) in place on nodes / node_time (int64 array, -1 = never updated).
+    animators[k] is (ANIM_SPIN, axis, rate), (ANIM_SWING, axis, rate, period) or a Python callable
+    f(time, last_time, trm) with trm a 9-float numpy view (scl, rot, pos) it changes in place."""
+    import numpy as np
+    assert nodes.dtype == node_dtype() and nodes.flags["C_CONTIGUOUS"] and node_time.dtype == np.int64
+    proto = ctypes.CFUNCTYPE(None, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p)
+    n = len(animators)
+    fns, users, keep = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_void_p * max(n, 1))(), []
+    for k, a in enumerate(animators):
+        if callable(a):
+            cb = proto(lambda t, lt, trm, _u, a=a: a(t, lt, np.ctypeslib.as_array(trm, shape=(9,))))
+            keep.append(cb)
+            fns[k] = ctypes.cast(cb, ctypes.c_void_p).value
+        else:
+            prm = _AnimParams(int(a[1]), float(a[2]), float(a[3]) if len(a) > 3 else 0.0, 0)
+            keep.append(prm)
+            fns[k] = ctypes.cast(lib().qr_anim_spin if a[0] == ANIM_SPIN else lib().qr_anim_swing, ctypes.c_void_p).value
+            users[k] = ctypes.addressof(prm)
+    _check(lib().qr_hierarchy_animate(nodes.ctypes.data_as(ctypes.c_void_p), len(nodes), int(time),
+                                      node_time.ctypes.data_as(ctypes.c_void_p), fns, users, n))
+
+
+def hierarchy_apply(blob, nodes, opts, camera=-1, base=None, flags=0):
+    """Write the transform fields the nodes imply into a copy of the snapshot (qr_hierarchy_apply); base: the nodes the
+    snapshot was captured with (enables the scope checks).  Rebuild the lists afterwards (build_lists)."""
+    import numpy as np
+    nodes = np.ascontiguousarray(nodes, dtype=node_dtype())
+    bp = None
+    if base is not None:
+        base = np.ascontiguousarray(base, dtype=node_dtype())
+        assert len(base) == len(nodes)
+        bp = base.ctypes.data_as(ctypes.c_void_p)
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    _check(lib().qr_hierarchy_apply(buf, len(blob), bp, nodes.ctypes.data_as(ctypes.c_void_p), len(nodes), opts, camera, flags,
+                                    ctypes.byref(out), ctypes.byref(n)))
     try:
         return ctypes.string_at(out, n.value)
     finally:

@@ -53,12 +53,14 @@ extern "C" uint64_t qr_frame_hash(const uint32_t *frame, uint64_t n_pixels)
     return h;
 }
 
+static thread_local QrFlattenMap g_capture_map;
+
 extern "C" int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, const char *path)
 {
     if (path == nullptr) return qr_fail(QR_ERR_ARG, "null path");
     std::vector<uint8_t> out;
     std::string err;
-    int rc = qr_flatten_impl(s_inf, abi, out, err);
+    int rc = qr_flatten_impl(s_inf, abi, out, err, &g_capture_map);
     if (rc != QR_OK) return qr_fail(rc, err);
     FILE *f = fopen(path, "wb");
     if (f == nullptr) return qr_fail(QR_ERR_IO, std::string("cannot open ") + path);
@@ -66,4 +68,13 @@ extern "C" int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, co
     int rc2 = fclose(f);
     if (n != out.size() || rc2 != 0) return qr_fail(QR_ERR_IO, std::string("short write to ") + path);
     return QR_OK;
+}
+
+extern "C" int qr_capture_index(int kind, const void *record)
+{
+    const std::vector<uint64_t> &v = kind == 0 ? g_capture_map.srf : g_capture_map.lgt;
+    const uint64_t key = (uint64_t)(uintptr_t)record;
+    if (key == 0 || (kind != 0 && kind != 1)) return -1;
+    for (size_t i = 0; i < v.size(); i++) if (v[i] == key) return (int)i;
+    return -1;
 }

@@ -1,0 +1,409 @@
+/*
+ * qr_hierarchy.cpp - animators and the hierarchical transform update (include/qr_hierarchy.h).
+ *
+ * Restates, over a flat parent-before-child node table, what the reference spreads over virtual
+ * update_object / update_matrix / update_fields of its object classes (core/engine/object.cpp, lines cited at
+ * each step).  fp32, one rounding per operation, the reference's operand order: the results are compared bit for
+ * bit with the engine's (tests/test_hierarchy.py).  Built with -ffp-contract=off.
+ */
+#include "qr_internal.h"
+#include "qr_hierarchy.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+enum { F_SCL = 1, F_ROT = 2, F_OBJ = 4 };       /* RT_UPDATE_FLAG_* (object.h:74-83) */
+
+typedef float M4[4][4];
+
+const M4 kIden = { {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1} };
+
+/* row r of the product is `a` applied to row r of `b` (matrix_mul_vector / matrix_mul_matrix, rtgeom.cpp:59-97):
+ * four products summed left to right */
+void mul(M4 out, const M4 a, const M4 b)
+{
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++)
+            out[r][c] = a[0][c] * b[r][0] + a[1][c] * b[r][1] + a[2][c] * b[r][2] + a[3][c] * b[r][3];
+}
+
+/* sine / cosine of an angle in degrees: exact at the multiples of 90 the engine treats as trivial, else the
+ * single-precision library function of the double-precision radians (RT_SINA32 / RT_COSA32, rtbase.h:584-600) */
+float sin_deg(float a)
+{
+    if (a == -270.0f || a == 90.0f) return 1.0f;
+    if (a == -90.0f || a == 270.0f) return -1.0f;
+    if (a == -180.0f || a == 0.0f || a == 180.0f) return 0.0f;
+    return sinf((float)((double)a * 3.14159265358979323846 / 180.0));
+}
+float cos_deg(float a)
+{
+    if (a == -180.0f || a == 180.0f) return -1.0f;
+    if (a == 0.0f) return 1.0f;
+    if (a == -270.0f || a == -90.0f || a == 90.0f || a == 270.0f) return 0.0f;
+    return cosf((float)((double)a * 3.14159265358979323846 / 180.0));
+}
+
+/* position * rot_z * rot_y * rot_x * scale, built right to left (matrix_from_transform, rtgeom.cpp:102-162) */
+void from_transform(M4 out, const qr_node &nd, bool with_scale)
+{
+    M4 sc, rx, ry, rz, ps, t0, t1;
+    memcpy(sc, kIden, sizeof(M4)); memcpy(rx, kIden, sizeof(M4)); memcpy(ry, kIden, sizeof(M4));
+    memcpy(rz, kIden, sizeof(M4)); memcpy(ps, kIden, sizeof(M4));
+    if (with_scale) { sc[0][0] = nd.scl[0]; sc[1][1] = nd.scl[1]; sc[2][2] = nd.scl[2]; }
+    const float sx = sin_deg(nd.rot[0]), cx = cos_deg(nd.rot[0]);
+    const float sy = sin_deg(nd.rot[1]), cy = cos_deg(nd.rot[1]);
+    const float sz = sin_deg(nd.rot[2]), cz = cos_deg(nd.rot[2]);
+    rx[1][1] = cx; rx[1][2] = sx; rx[2][1] = -sx; rx[2][2] = cx;
+    ry[0][0] = cy; ry[0][2] = -sy; ry[2][0] = sy; ry[2][2] = cy;
+    rz[0][0] = cz; rz[0][1] = sz; rz[1][0] = -sz; rz[1][1] = cz;
+    ps[3][0] = nd.pos[0]; ps[3][1] = nd.pos[1]; ps[3][2] = nd.pos[2];
+    mul(t0, rx, sc);
+    mul(t1, ry, t0);
+    mul(t0, rz, t1);
+    mul(out, ps, t0);
+}
+
+/* inverse of the upper-left 3x3 by cofactors (matrix_inverse, rtgeom.cpp:167-193) */
+void inverse3(M4 out, const M4 m)
+{
+    memset(out, 0, sizeof(M4));
+    const float a = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    const float b = m[2][1] * m[0][2] - m[0][1] * m[2][2];
+    const float c = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+    const float d = m[2][0] * m[1][2] - m[1][0] * m[2][2];
+    const float e = m[0][0] * m[2][2] - m[2][0] * m[0][2];
+    const float f = m[0][2] * m[1][0] - m[0][0] * m[1][2];
+    const float g = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    const float h = m[2][0] * m[0][1] - m[0][0] * m[2][1];
+    const float l = m[0][0] * m[1][1] - m[1][0] * m[0][1];
+    const float q = 1.0f / (m[0][0] * a + m[1][0] * b + m[2][0] * c);
+    out[0][0] = a * q; out[0][1] = b * q; out[0][2] = c * q;
+    out[1][0] = d * q; out[1][1] = e * q; out[1][2] = f * q;
+    out[2][0] = g * q; out[2][1] = h * q; out[2][2] = l * q;
+}
+
+/* what a node hands to its children (rt_Array::update_object, object.cpp:1739-1756) */
+struct Pass { int flags; int trnode; M4 mtx; };
+
+bool all_in(const float v[3], const float *set, int n)
+{
+    int hits = 0;
+    for (int k = 0; k < n; k++) for (int a = 0; a < 3; a++) if (v[a] == set[k]) hits++;
+    return hits == 3;
+}
+
+void set_identity_map(qr_node_state &s, float sx, float sy, float sz)
+{
+    for (int i = 0; i < 4; i++) { s.map[i] = i; s.sgn[i] = 1; }
+    s.scl[0] = sx; s.scl[1] = sy; s.scl[2] = sz; s.scl[3] = 1.0f;
+}
+
+/* update_status + update_matrix of one object (object.cpp:175-389); `in` is what the parent passed down */
+void update_node(const qr_node &nd, int self, const Pass &in, const qr_node_state *all, uint32_t opts, qr_node_state &s)
+{
+    static const float unit_scl[] = { -1.0f, 1.0f };
+    static const float right_rot[] = { -270.0f, -180.0f, -90.0f, 0.0f, 90.0f, 180.0f, 270.0f };
+    M4 &mtx = *(M4 *)s.mtx;
+    M4 own, tmp;
+
+    /* update_status 204-213: transform flags and trnode come from the hierarchy (every call is a full update) */
+    s.obj_has_trm = in.flags & (F_SCL | F_ROT);
+    s.trnode = in.trnode;
+    set_identity_map(s, 1.0f, 1.0f, 1.0f);      /* the engine leaves them as they were; a trivial matrix sets all of them below */
+
+    /* 236-262: is the object's own transform trivial (unit scalers, right-angle rotation)? */
+    s.mtx_has_trm = 0;
+    if (!all_in(nd.scl, unit_scl, 2)) s.mtx_has_trm |= F_SCL;
+    if (!all_in(nd.rot, right_rot, 7)) s.mtx_has_trm |= F_ROT;
+
+    if (!(s.mtx_has_trm & F_ROT))
+    {
+        /* 265-304: no rotation of its own: the matrix stays an axis permutation with signs and scalers */
+        from_transform(own, nd, true);
+        mul(mtx, in.mtx, own);
+        if (s.obj_has_trm == F_SCL) { s.mtx_has_trm = s.obj_has_trm; s.obj_has_trm = 0; }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+            {
+                bool same = true;       /* row i has its non-zeros where row j of the identity has them */
+                for (int c = 0; c < 3; c++) same = same && ((mtx[i][c] != 0.0f) == (c == j));
+                if (same)
+                {
+                    s.map[i] = j;
+                    s.sgn[i] = mtx[i][j] < 0.0f ? -1 : mtx[i][j] > 0.0f ? 1 : 0;
+                    s.scl[j] = fabsf(mtx[i][j]);
+                }
+            }
+        s.map[3] = 3; s.sgn[3] = 1; s.scl[3] = 1.0f;
+    }
+    else
+    {
+        /* 307-341: a rotation of its own makes the object a transform node; scalers stay out of the matrix,
+         * the solvers apply them; under another trnode the matrix is taken to world space first */
+        from_transform(own, nd, false);
+        if (s.trnode < 0) mul(mtx, in.mtx, own);
+        else
+        {
+            mul(tmp, *(const M4 *)all[s.trnode].mtx, in.mtx);
+            mul(mtx, tmp, own);
+        }
+        s.trnode = self;
+        s.obj_has_trm |= F_ROT;
+        set_identity_map(s, nd.scl[0], nd.scl[1], nd.scl[2]);
+    }
+
+    /* 343-350: without the FSCALE optimisation a rotated object is treated as scaled too */
+    if ((s.obj_has_trm & F_ROT) && !(opts & QR_OPTS_FSCALE)) s.obj_has_trm |= F_SCL;
+
+    /* 352-381: cameras and lights (and, without transform caching, everything) do not stay relative to a trnode:
+     * their matrix goes to world space and they become their own */
+    if (s.trnode >= 0 && s.trnode != self && (!(opts & QR_OPTS_TARRAY) || nd.tag > QR_TAG_SURFACE_MAX))
+    {
+        mul(tmp, *(const M4 *)all[s.trnode].mtx, mtx);
+        memcpy(mtx, tmp, sizeof(M4));
+        s.trnode = self;
+        s.obj_has_trm |= s.mtx_has_trm;
+        set_identity_map(s, 1.0f, 1.0f, 1.0f);
+    }
+}
+
+int run_update(const qr_node *nodes, int32_t n, uint32_t opts, qr_node_state *out, std::string &err)
+{
+    if (nodes == nullptr || out == nullptr || n <= 0) { err = "bad node table"; return QR_ERR_ARG; }
+    std::vector<Pass> pass((size_t)n);
+    for (int i = 0; i < n; i++)
+    {
+        const qr_node &nd = nodes[i];
+        if (nd.parent >= i || nd.parent < -1) { err = "node " + std::to_string(i) + ": parents must precede children"; return QR_ERR_ARG; }
+        if (nd.parent >= 0 && nodes[nd.parent].tag != QR_NODE_ARRAY) { err = "node " + std::to_string(i) + ": parent is not an array"; return QR_ERR_ARG; }
+        Pass root; root.flags = 0; root.trnode = -1; memcpy(root.mtx, kIden, sizeof(M4));
+        const Pass &in = nd.parent < 0 ? root : pass[(size_t)nd.parent];
+        memset(&out[i], 0, sizeof(qr_node_state));
+        update_node(nd, i, in, out, opts, out[i]);
+        if (nd.tag == QR_NODE_ARRAY)
+        {
+            /* rt_Array::update_matrix 1708-1733 + update_object 1750-1755: children get the array's matrix, or, under
+             * an array that is a transform node, only its scalers; and its flags on top of the inherited ones */
+            Pass &p = pass[(size_t)i];
+            p.flags = in.flags | out[i].mtx_has_trm | F_OBJ;
+            p.trnode = out[i].trnode;
+            if (out[i].trnode == i)
+            {
+                memcpy(p.mtx, kIden, sizeof(M4));
+                p.mtx[0][0] = out[i].scl[0]; p.mtx[1][1] = out[i].scl[1]; p.mtx[2][2] = out[i].scl[2];
+            }
+            else memcpy(p.mtx, out[i].mtx, sizeof(M4));
+        }
+    }
+    return QR_OK;
+}
+
+bool is_surface(int tag) { return tag >= 0 && tag < QR_TAG_SURFACE_MAX; }
+
+/* a_map / a_sgn / trnode of a surface or array record (rt_Surface::update_fields 2486-2502, rt_Array 1770-1788) */
+void put_mapping(qr_surface &r, const qr_node_state &s, const qr_node *nodes)
+{
+    r.has_trm = s.obj_has_trm;
+    r.shift = s.trnode >= 0 ? 1 : 0;
+    r.axes = (uint32_t)(s.map[0] & 3) | (uint32_t)(s.map[1] & 3) << 2 | (uint32_t)(s.map[2] & 3) << 4
+           | (s.sgn[0] >= 0 ? 0u : 1u) << 8 | (s.sgn[1] >= 0 ? 0u : 1u) << 9 | (s.sgn[2] >= 0 ? 0u : 1u) << 10;
+    r.trnode = s.trnode >= 0 ? nodes[s.trnode].srf : QR_NULL;
+}
+
+/* quadric coefficients: shape in local axes (update_fields of the nine shapes, 3120-3910), then the scalers
+ * (rt_Quadric::commit_fields 3034-3063) */
+void put_quadric(qr_surface &r, const qr_node &nd, const qr_node_state &s)
+{
+    float sci[4] = { 1.0f, 1.0f, 1.0f, 0.0f }, scj[3] = { 0.0f, 0.0f, 0.0f };
+    const int mi = s.map[0], mj = s.map[1], mk = s.map[2];
+    const float sk = (float)s.sgn[2];
+    switch (nd.tag)
+    {
+    case 1: sci[mk] = 0.0f; sci[3] = nd.shape[0] * nd.shape[0]; break;                       /* cylinder        */
+    case 2: sci[3] = nd.shape[0] * nd.shape[0]; break;                                       /* sphere          */
+    case 3: sci[mk] = -(nd.shape[0] * nd.shape[0]); break;                                   /* cone            */
+    case 4: sci[mk] = 0.0f; scj[mk] = nd.shape[0] * sk; break;                               /* paraboloid      */
+    case 5: sci[mk] = -(nd.shape[0] * nd.shape[0]); sci[3] = nd.shape[1]; break;             /* hyperboloid     */
+    case 6: sci[mj] = 0.0f; sci[mk] = 0.0f; scj[mk] = nd.shape[0] * sk; break;               /* paracylinder    */
+    case 7: sci[mj] = 0.0f; sci[mk] = -(nd.shape[0] * nd.shape[0]); sci[3] = nd.shape[1]; break; /* hypercylinder */
+    case 8: sci[mi] = 1.0f / +fabsf(nd.shape[0]); sci[mj] = 1.0f / -fabsf(nd.shape[1]);      /* hyperparaboloid */
+            sci[mk] = 0.0f; scj[mk] = 1.0f * sk; break;
+    default: return;
+    }
+    float isc[3];
+    for (int a = 0; a < 3; a++) isc[a] = 1.0f / s.scl[a];
+    for (int a = 0; a < 3; a++)
+    {
+        sci[a] *= isc[a] * isc[a];
+        scj[a] *= isc[a];
+    }
+    for (int a = 0; a < 4; a++) r.sci[a] = sci[a];
+    for (int a = 0; a < 3; a++) r.scj[a] = scj[a] * 0.5f;
+}
+
+bool same_bits(const void *a, const void *b, size_t n) { return memcmp(a, b, n) == 0; }
+
+} /* namespace */
+
+extern "C" int qr_hierarchy_update(const qr_node *nodes, int32_t n, uint32_t opts, qr_node_state *out)
+{
+    std::string err;
+    const int rc = run_update(nodes, n, opts, out, err);
+    return rc == QR_OK ? QR_OK : qr_fail(rc, err);
+}
+
+extern "C" int qr_hierarchy_animate(qr_node *nodes, int32_t n, int64_t time, int64_t *node_time,
+                                    const qr_anim_fn *fns, void *const *users, int32_t n_fns)
+{
+    if (nodes == nullptr || node_time == nullptr || n <= 0) return qr_fail(QR_ERR_ARG, "bad node table");
+    for (int i = 0; i < n; i++)
+    {
+        const int k = nodes[i].anim;
+        if (k >= 0)
+        {
+            if (fns == nullptr || k >= n_fns || fns[k] == nullptr) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": no animator in slot " + std::to_string(k));
+            /* object.cpp:182-190: once per time value, the first call sees last_time 0 */
+            if (node_time[i] != time) fns[k](time, node_time[i] < 0 ? 0 : node_time[i], nodes[i].scl, users ? users[k] : nullptr);
+        }
+        node_time[i] = time;
+    }
+    return QR_OK;
+}
+
+extern "C" void qr_anim_spin(int64_t time, int64_t last_time, float *trm, void *user)
+{
+    const qr_anim_params *p = (const qr_anim_params *)user;
+    float *rot = trm + 3;
+    const float t = (float)(time - last_time) / 50.0f;
+    rot[p->axis] += t * p->rate;
+    if (rot[p->axis] >= 360.0f) rot[p->axis] -= 360.0f;
+}
+
+extern "C" void qr_anim_swing(int64_t time, int64_t, float *trm, void *user)
+{
+    const qr_anim_params *p = (const qr_anim_params *)user;
+    const float t = (float)time / p->period;
+    trm[3 + p->axis] = (float)((double)p->rate * sin((double)t));
+}
+
+extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node *base, const qr_node *next, int32_t n,
+                                  uint32_t opts, int32_t camera, uint32_t flags, void **out_blob, uint64_t *out_size)
+{
+    if (blob == nullptr || next == nullptr || out_blob == nullptr || out_size == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    qr_scene_view v;
+    if (qr_scene_view_init(&v, blob, size) != 0) return qr_fail(QR_ERR_ARG, "not a snapshot");
+    std::string err;
+    int rc = qr_snapshot_validate(v, err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    std::vector<qr_node_state> st((size_t)(n > 0 ? n : 0)), st0;
+    rc = run_update(next, n, opts, st.data(), err);
+    if (rc != QR_OK) return qr_fail(rc, err);
+    const int n_srf = (int)v.hdr->n_srf, n_lgt = (int)v.hdr->n_lgt;
+    for (int i = 0; i < n; i++)
+    {
+        const qr_node &nd = next[i];
+        const int refs[3] = { nd.srf, nd.tag == QR_NODE_ARRAY ? nd.inb : -1, nd.tag == QR_NODE_ARRAY ? nd.bvb : -1 };
+        for (int r : refs) if (r < -1 || r >= n_srf) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": surface record out of range");
+        if (nd.tag == QR_NODE_LIGHT && (nd.lgt < -1 || nd.lgt >= n_lgt)) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": light record out of range");
+        if (st[(size_t)i].trnode >= 0 && st[(size_t)i].trnode != i && (is_surface(nd.tag) || nd.tag == QR_NODE_ARRAY) && nd.srf >= 0
+            && next[st[(size_t)i].trnode].srf < 0)
+            return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": its transform node has no record in the snapshot");
+    }
+    if (camera >= n || (camera >= 0 && next[camera].tag != QR_NODE_CAMERA)) return qr_fail(QR_ERR_ARG, "camera is not a camera node");
+
+    if (base != nullptr)
+    {
+        /* the scope of a frame-to-frame update (qr_hierarchy.h): same transform nodes, same axis mappings and scalers,
+         * no moving bounding volume */
+        st0.resize((size_t)n);
+        rc = run_update(base, n, opts, st0.data(), err);
+        if (rc != QR_OK) return qr_fail(rc, err);
+        std::vector<char> moved((size_t)n, 0);
+        for (int i = 0; i < n; i++)
+        {
+            const qr_node_state &a = st0[(size_t)i], &b = st[(size_t)i];
+            if (base[i].parent != next[i].parent || base[i].tag != next[i].tag || base[i].srf != next[i].srf || base[i].lgt != next[i].lgt)
+                return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": the two node tables describe different trees");
+            const bool has_record = (is_surface(next[i].tag) || next[i].tag == QR_NODE_ARRAY) && next[i].srf >= 0;
+            if (has_record && (a.trnode != b.trnode || a.obj_has_trm != b.obj_has_trm))
+                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
+            if (has_record &&
+                (!same_bits(a.map, b.map, sizeof(a.map)) || !same_bits(a.sgn, b.sgn, sizeof(a.sgn)) || !same_bits(a.scl, b.scl, sizeof(a.scl))))
+                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": axis mapping or scalers change (clip boxes would)");
+            moved[(size_t)i] = !same_bits(a.mtx, b.mtx, sizeof(a.mtx));
+        }
+        for (int i = n - 1; i >= 0; i--)
+        {
+            if (moved[(size_t)i] && next[i].parent >= 0) moved[(size_t)next[i].parent] = 1;  /* children come later: one sweep */
+            if (next[i].tag == QR_NODE_ARRAY && moved[(size_t)i] && (next[i].inb >= 0 || next[i].bvb >= 0))
+                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": an array with a bounding volume moves");
+        }
+    }
+
+    std::vector<uint8_t> out((const uint8_t *)blob, (const uint8_t *)blob + v.hdr->total_bytes);
+    qr_surface *S = (qr_surface *)(out.data() + v.hdr->off_srf);
+    qr_light *L = (qr_light *)(out.data() + v.hdr->off_lgt);
+    qr_frame *F = (qr_frame *)(out.data() + v.hdr->off_frame);
+    for (int i = 0; i < n; i++)
+    {
+        const qr_node &nd = next[i];
+        const qr_node_state &s = st[(size_t)i];
+        const M4 &m = *(const M4 *)s.mtx;
+        if ((is_surface(nd.tag) || nd.tag == QR_NODE_ARRAY) && nd.srf >= 0)
+        {
+            qr_surface &r = S[nd.srf];
+            /* rt_Node::update_fields 813-843: transform nodes carry the inverse matrix; everybody its position */
+            if (s.trnode == i)
+            {
+                M4 inv;
+                inverse3(inv, m);
+                for (int c = 0; c < 3; c++) { r.tci[c] = inv[c][0]; r.tcj[c] = inv[c][1]; r.tck[c] = inv[c][2]; }
+            }
+            r.pos[0] = m[3][0]; r.pos[1] = m[3][1]; r.pos[2] = m[3][2];
+            put_mapping(r, s, next);
+            if (is_surface(nd.tag)) put_quadric(r, nd, s);
+        }
+        /* the records of an array's bounding volumes (nd.inb, nd.bvb) are left alone: rt_Array::update_bounds
+         * (object.cpp:1830-2316) owns them and overrides what update_fields wrote (2268-2280) */
+        if (nd.tag == QR_NODE_LIGHT && nd.lgt >= 0)
+        {
+            /* rt_Light::update_fields 649-667 */
+            L[nd.lgt].pos[0] = m[3][0]; L[nd.lgt].pos[1] = m[3][1]; L[nd.lgt].pos[2] = m[3][2];
+        }
+    }
+    if (camera >= 0)
+    {
+        /* rt_Scene::render, engine.cpp:3029-3043, 3256-3260: rays start at the camera position and aim at the centre
+         * of the top-left pixel of a screen `pov` in front of it; hor / ver step one pixel */
+        const M4 &m = *(const M4 *)st[(size_t)camera].mtx;
+        const float factor = 1.0f / (float)F->frm_w, aspect = (float)F->frm_h * factor;
+        const float h = -0.5f * 1.0f, w = -0.5f * aspect, pov = next[camera].pov;
+        float dir[3], hor[3], ver[3];
+        for (int c = 0; c < 3; c++)
+        {
+            dir[c] = m[2][c] * pov;
+            dir[c] += m[0][c] * h;
+            dir[c] += m[1][c] * w;
+            hor[c] = m[0][c] * factor;
+            ver[c] = m[1][c] * factor;
+            dir[c] += hor[c] * 0.5f;
+            dir[c] += ver[c] * 0.5f;
+            F->dir[c] = dir[c]; F->hor[c] = hor[c]; F->ver[c] = ver[c]; F->org[c] = m[3][c];
+        }
+    }
+    if (flags & QR_HIER_RESET_TILES)
+    {
+        int32_t *T = (int32_t *)(out.data() + v.hdr->off_tiles);
+        for (uint32_t k = 0; k < v.hdr->n_tiles; k++) T[k] = F->clist;
+    }
+    void *p = malloc(out.size());
+    if (p == nullptr) return qr_fail(QR_ERR_NOMEM, "out of memory");
+    memcpy(p, out.data(), out.size());
+    *out_blob = p;
+    *out_size = out.size();
+    return QR_OK;
+}

@@ -13,8 +13,9 @@
 #include <cstdint>
 
 /* flatten the rt_SIMD_INFOX graph into a qr_scene.h blob (qr_walker.cpp) */
+struct QrFlattenMap { std::vector<uint64_t> srf, lgt; };    /* address of the engine's record, by snapshot index */
 int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi,
-                    std::vector<uint8_t> &out, std::string &err);
+                    std::vector<uint8_t> &out, std::string &err, QrFlattenMap *map = nullptr);
 
 /* thread-local error channel behind qr_last_error() (qr_capi_host.cpp) */
 void qr_set_error(const std::string &msg);

@@ -110,6 +110,11 @@ public:
         keys[j] = key; vals[j] = val;
     }
     int32_t at(uint64_t key) const { const int32_t *p = find(key); return p ? *p : QR_NULL; }
+    void by_index(std::vector<uint64_t> &out, size_t n) const      /* out[value] = key */
+    {
+        out.assign(n, 0);
+        for (size_t j = 0; j < keys.size(); j++) if (keys[j] && (size_t)vals[j] < n) out[(size_t)vals[j]] = keys[j];
+    }
 };
 
 struct Walker
@@ -424,7 +429,7 @@ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 } /* namespace */
 
-int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8_t> &out, std::string &err)
+int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8_t> &out, std::string &err, QrFlattenMap *map)
 {
     if (s_inf == nullptr || abi == nullptr) { err = "null argument"; return QR_ERR_ARG; }
     if (abi->struct_size != sizeof(qr_abi_desc)) { err = "qr_abi_desc size mismatch"; return QR_ERR_ABI; }
@@ -552,5 +557,11 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     if (!tiles.empty())    memcpy(out.data() + h.off_tiles, tiles.data(), tiles.size() * 4);
     if (!w.texels.empty()) memcpy(out.data() + h.off_texels, w.texels.data(), w.texels.size() * 4);
     phase("assemble");
+    if (map != nullptr)
+    {
+        /* which engine record became which snapshot index (qr_capture_index) */
+        w.srf_ix.by_index(map->srf, w.srf.size());
+        w.lgt_ix.by_index(map->lgt, w.lgt.size());
+    }
     return QR_OK;
 }

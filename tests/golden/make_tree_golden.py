@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Generate the object-hierarchy fixtures under tests/golden/tree/ (run in the build container only).
+
+For every small case of manifest.json the UNMODIFIED reference (oracle/_ref/qr_ref_shim) renders the frame again and
+dumps its object tree (oracle/ref_driver.cpp --tree): per object the inputs of the hierarchical update (parent, tag,
+scale / rotation / position after the animators ran, shape parameters) and what the engine computed from them (matrix,
+transform node, flags), plus the snapshot index of every record the object owns.  The snapshot of that run must equal the
+committed one byte for byte, so the indices are valid for it.
+    tree/<case>.json.gz        the tree of an existing case
+    tree/<extra>.json.gz + tree/<extra>.frame.npy.gz   further animation times of the demo scenes: tree and reference frame
+                               only (tests patch the snapshot of another time of the same scene and must get this frame)
+Data only: numbers the engine computed; nothing of the reference's source text is stored.
+"""
+import gzip, io, json, os, subprocess, sys, tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+OUT = os.path.join(HERE, "tree")
+
+# name -> (scene, args): frames at other times, same options as an existing snapshot of the scene
+EXTRA = {
+    "demo01_160_t2500": ("demo01", ["-t", "2500"]),                             # base: demo01_160_t12345
+    "demo01_160_gf_t2500": ("demo01", ["--gamma", "--fresnel", "-t", "2500"]),  # base: demo01_160_gf_t5000
+    "demo03_160_t3000": ("demo03", ["-t", "3000"]),                             # base: demo03_160 (camera animator only)
+}
+
+
+def run(scene, w, h, args, tmp):
+    raw, qrs, tree = (os.path.join(tmp, n) for n in ("f.raw", "s.qrs", "t.json"))
+    cmd = [REF, "--scene", scene, "-w", str(w), "-h", str(h), "--out", raw, "--snapshot", qrs, "--tree", tree] + args
+    out = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError(f"{scene}: {out.stdout}{out.stderr}")
+    frame = np.fromfile(raw, dtype="<u4").reshape(h, w) & 0xFFFFFF
+    return frame, open(qrs, "rb").read(), open(tree, "rb").read()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+    for name, m in sorted(manifest.items()):
+        if m["w"] > 640:
+            continue
+        tmp = tempfile.mkdtemp(prefix="qrtree_")
+        _, blob, tree = run(m["scene"], m["w"], m["h"], m["args"], tmp)
+        committed = gzip.decompress(open(os.path.join(HERE, m["snapshot"]), "rb").read())
+        if blob != committed:
+            raise RuntimeError(f"{name}: the snapshot of this run differs from the committed one")
+        with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
+            f.write(gzip.compress(tree, 9, mtime=0))
+        print(name, len(json.loads(tree)["nodes"]), "nodes")
+    for name, (scene, args) in sorted(EXTRA.items()):
+        tmp = tempfile.mkdtemp(prefix="qrtree_")
+        frame, _, tree = run(scene, 160, 120, args, tmp)
+        with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
+            f.write(gzip.compress(tree, 9, mtime=0))
+        bio = io.BytesIO(); np.save(bio, frame.astype("<u4"))
+        with open(os.path.join(OUT, name + ".frame.npy.gz"), "wb") as f:
+            f.write(gzip.compress(bio.getvalue(), 9, mtime=0))
+        print(name, "frame + tree")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+"""Object hierarchy and animators (include/qr_hierarchy.h, SURVEY.md 8f row 4: rt_Object::update_matrix, object.cpp:221-389).
+
+Fixtures: tests/golden/tree/*.json.gz, dumped from the unmodified reference engine after a frame (oracle/ref_driver.cpp
+--tree, tests/golden/make_tree_golden.py): per object the inputs of the hierarchical update and the engine's results.
+The bar is bit-exact fp32: matrices, transform nodes and flags per object; every transform field of the snapshot of the
+same frame; and, end to end, the reference's frame at another animation time from a snapshot patched by this module."""
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MANIFEST, load_blob, load_frame
+
+TREE = os.path.join(GOLDEN, "tree")
+CASES = sorted(n[:-8] for n in os.listdir(TREE) if n.endswith(".json.gz") and n[:-8] in MANIFEST)
+
+# (snapshot + tree the scene is patched from, tree of the target time, where the reference's frame of that time is)
+ANIMATED = [
+    ("demo01_160_t12345", "demo01_160_t2500", "tree"),
+    ("demo01_160_gf_t5000", "demo01_160_gf_t2500", "tree"),
+    ("demo02_160_gf_t5000", "demo02_160_t7777_gf", "golden"),
+    ("demo03_160", "demo03_160_t3000", "tree"),
+]
+
+
+def _f32(words):
+    return np.array([int(x, 16) for x in words], dtype=np.uint32).view(np.float32)
+
+
+def load_tree(qr, name):
+    with open(os.path.join(TREE, name + ".json.gz"), "rb") as f:
+        t = json.loads(gzip.decompress(f.read()))
+    nodes = np.zeros(len(t["nodes"]), dtype=qr.node_dtype())
+    for i, n in enumerate(t["nodes"]):
+        r = nodes[i]
+        r["parent"], r["tag"] = n["parent"], n["tag"]
+        r["scl"], r["rot"], r["pos"], r["shape"] = _f32(n["scl"]), _f32(n["rot"]), _f32(n["pos"]), _f32(n["shape"])
+        r["srf"], r["inb"], r["bvb"], r["lgt"] = n.get("srf", -1), n.get("inb", -1), n.get("bvb", -1), n.get("lgt", -1)
+        r["anim"] = -1
+        if "pov" in n:
+            r["pov"] = _f32(n["pov"])[0]
+    return t, nodes
+
+
+def tree_frame(name):
+    with open(os.path.join(TREE, name + ".frame.npy.gz"), "rb") as f:
+        return np.load(io.BytesIO(gzip.decompress(f.read())))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_update_and_fields_match_the_engine(qr, name):
+    """Per object: matrix (bit for bit), transform node, transform flags.  Then the snapshot of the same frame: writing
+    the fields the nodes imply (position, inverse matrices, axis maps, quadric coefficients, light positions, camera
+    vectors) must change nothing."""
+    t, nodes = load_tree(qr, name)
+    st = qr.hierarchy_update(nodes, t["opts"])
+    for i, n in enumerate(t["nodes"]):
+        assert (bits(st[i]["mtx"]) == bits(_f32(n["mtx"]))).all(), (i, n["tag"])
+        assert (st[i]["trnode"], st[i]["obj_has_trm"], st[i]["mtx_has_trm"]) == (n["trnode"], n["obj_has_trm"], n["mtx_has_trm"]), i
+    blob = load_blob(name)
+    assert qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"]) == blob
+    assert qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"], base=nodes) == blob
+
+
+def _animators(t):
+    """The demo scenes' animators as data: the array above the camera turns 1 degree per 50 ms (demo01) or swings
+    15 degrees with sin(t / 1500) (demo03); the array above a light turns 7 degrees per 50 ms (demo01, demo02)."""
+    slots, anim = [], {}
+    for i, n in enumerate(t["nodes"]):
+        if n["anim"]:
+            kids = [c["tag"] for c in t["nodes"] if c["parent"] == i]
+            if 100 in kids:
+                slots.append(("swing", 2, 15.0, 1500.0) if t["scene"] == "demo03" else ("spin", 2, 1.0))
+            else:
+                slots.append(("spin", 2, 7.0))
+            anim[i] = len(slots) - 1
+    return slots, anim
+
+
+@pytest.mark.parametrize("start,target", [("demo01_160", "demo01_160_t2500"), ("demo01_160", "demo01_160_gf_t5000"),
+                                          ("demo01_160", "demo01_160_t12345"), ("demo02_160", "demo02_160_t7777_gf"),
+                                          ("demo03_160", "demo03_160_t3000"), ("demo03_160", "demo03_160_t9999_aa4")])
+def test_animators_move_the_nodes_like_the_engines(qr, start, target):
+    t0, nodes = load_tree(qr, start)
+    t1, want = load_tree(qr, target)
+    slots, anim = _animators(t0)
+    assert anim, "the scene has animators"
+    for i, k in anim.items():
+        nodes[i]["anim"] = k
+    times = np.full(len(nodes), -1, dtype=np.int64)
+    qr.hierarchy_animate(nodes, t1["time"], times, slots)
+    for f in ("scl", "rot", "pos"):
+        assert (bits(nodes[f]) == bits(want[f])).all(), f
+    assert (times == t1["time"]).all()
+    before = nodes.copy()
+    qr.hierarchy_animate(nodes, t1["time"], times, slots)          # same time again: animators are not called twice
+    assert nodes.tobytes() == before.tobytes()
+    # a Python callable in a slot sees (time, last_time, the nine floats)
+    seen = []
+    fresh = load_tree(qr, start)[1]
+    for i in anim:
+        fresh[i]["anim"] = 0
+
+    def cb(time, last, trm):
+        seen.append((time, last))
+        trm[3 + 2] += 1.0
+
+    qr.hierarchy_animate(fresh, 40, np.full(len(fresh), 7, dtype=np.int64), [cb])
+    assert seen == [(40, 7)] * len(anim)
+
+
+def _patched(qr, base_name, target_name):
+    tb, base = load_tree(qr, base_name)
+    tt, tgt = load_tree(qr, target_name)
+    assert len(base) == len(tgt) and (base["parent"] == tgt["parent"]).all() and (base["tag"] == tgt["tag"]).all()
+    nxt = base.copy()                       # the base snapshot's record indices, the target time's transforms
+    for f in ("scl", "rot", "pos"):
+        nxt[f] = tgt[f]
+    blob = qr.hierarchy_apply(load_blob(base_name), nxt, tb["opts"], camera=tb["camera"], base=base, flags=qr.HIER_RESET_TILES)
+    return qr.build_lists(blob)
+
+
+def _target_frame(target_name, where):
+    return (tree_frame(target_name) if where == "tree" else load_frame(target_name)) & 0xFFFFFF
+
+
+@pytest.mark.parametrize("base_name,target_name,where", ANIMATED)
+def test_animated_snapshot_gives_the_reference_frame_of_that_time(qr, oracle, base_name, target_name, where):
+    """Snapshot of one time + the hierarchy at another time -> apply -> rebuilt lists -> the oracle renders the
+    reference's frame of that other time, pixel for pixel."""
+    built = _patched(qr, base_name, target_name)
+    frame, _, _ = oracle.render(built, threads=8)
+    assert (frame == _target_frame(target_name, where)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base_name,target_name,where", ANIMATED)
+def test_gpu_animated_snapshot_gives_the_reference_frame_of_that_time(qr, base_name, target_name, where):
+    built = _patched(qr, base_name, target_name)
+    sc = qr.Scene(built, rebin_tiles=True)
+    frame = sc.render().cpu().numpy().view(np.uint32) & 0xFFFFFF
+    assert (frame == _target_frame(target_name, where)).all()
+
+
+def test_updates_outside_the_scope_are_refused(qr):
+    """demo01 at t = 0: the light's array is not rotated yet; at t = 2500 it is a transform node, the bulb's record needs a
+    trnode the snapshot has no record and no list element for -- the engine rebuilds its lists there, apply refuses."""
+    t0, base = load_tree(qr, "demo01_160")
+    _, tgt = load_tree(qr, "demo01_160_t2500")
+    nxt = base.copy()
+    for f in ("scl", "rot", "pos"):
+        nxt[f] = tgt[f]
+    with pytest.raises(qr.QrError, match="transform node"):
+        qr.hierarchy_apply(load_blob("demo01_160"), nxt, t0["opts"], camera=t0["camera"], base=base)
+    # a right-angle turn of a clipped surface changes its axis mapping: the clip box would have to be rebuilt
+    tb, b13 = load_tree(qr, "test13_160")
+    k = next(i for i in range(len(b13)) if 0 <= b13[i]["tag"] < 9 and b13[i]["srf"] >= 0)
+    turned = b13.copy()
+    turned[k]["rot"][0] += 90.0
+    with pytest.raises(qr.QrError, match="axis mapping|transform node"):
+        qr.hierarchy_apply(load_blob("test13_160"), turned, tb["opts"], base=b13)
+    # malformed tables
+    bad = b13.copy()
+    bad[1]["parent"] = 5
+    with pytest.raises(qr.QrError, match="precede"):
+        qr.hierarchy_update(bad, tb["opts"])
+    bad = b13.copy()
+    bad[k]["srf"] = 100000
+    with pytest.raises(qr.QrError, match="out of range"):
+        qr.hierarchy_apply(load_blob("test13_160"), bad, tb["opts"])
