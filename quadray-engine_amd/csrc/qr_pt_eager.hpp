@@ -38,6 +38,7 @@ __device__ __forceinline__ V3 pt_eager(const Ctx &cx, const Ray &primary, bool i
     V3 rdir = {0, 0, 0}; u32 lst_rf = 0; int want_rf = 0;
     int phase = 0;                              /* which child the level waits for: 1 bounce, 2 refraction, 3 reflection */
     int mode = inside ? (pos != 0 ? M_WALK : M_END) : M_DONE;
+    bool rr_dead = false;
     u32 p_op = 0, p_srf = 0;
     V3 ret = {0, 0, 0};
     Counters cnt = {0, 0, 0, 0};
@@ -70,6 +71,7 @@ __device__ __forceinline__ V3 pt_eager(const Ctx &cx, const Ray &primary, bool i
         lst_rf = f2u(f[43]); want_rf = (int)f2u(f[44]); phase = (int)f2u(f[45]);
         dd = cur.dir.x * cur.dir.x + cur.dir.y * cur.dir.y + cur.dir.z * cur.dir.z;
         w.tbd = w.tbuf * dd; w.resume = 0;
+        rr_dead = false;                                    /* a level that spawned a child had survived */
     };
     /* a child ray of the hit being shaded starts its own level */
     auto spawn = [&](V3 dir, u32 list, int flg, int ph) {
@@ -196,6 +198,7 @@ __device__ __forceinline__ V3 pt_eager(const Ctx &cx, const Ray &primary, bool i
             {
                 acc = o.col;                                /* the material's emission */
                 ptex = o.ptex; pldff = o.pldff;
+                rr_dead = o.rr_dead;                        /* no spawn follows a dead sample: stage 2 comes next, same level */
                 if (o.want_pt && (depth - level) != 0) spawn(o.pdir, o.lst_pt, h.side, 1);
                 else mode = M_SHADE2;
             }
@@ -206,7 +209,7 @@ __device__ __forceinline__ V3 pt_eager(const Ctx &cx, const Ray &primary, bool i
         {
             Shaded o;
             if (rt_shading) shade<false, false, false>(cx, mode == M_SHADE2, false, cur, h, o, cnt);
-            else shade<false, false, true>(cx, mode == M_SHADE2, false, cur, h, o, cnt, &rng, depth - level, 2);
+            else shade<false, false, true>(cx, mode == M_SHADE2, false, cur, h, o, cnt, &rng, depth - level, rr_dead ? 3 : 2);
             if (mode == M_SHADE2)
             {
                 c_trn = o.c_trn; c_rfl = o.c_rfl; x0 = o.x0; rdir = o.rdir; lst_rf = o.lst_rf; want_rf = o.want_rf ? 1 : 0;

@@ -46,6 +46,7 @@ struct Shaded
     V3 ptw;                 /* l_dff * texture colour (after Russian roulette): weight of what it returns */
     V3 ptex; float pldff;   /* the two factors apart (the eager path tracer multiplies in the reference's order) */
     u32 lst_pt;             /* its list: the surface's own side, LST_P(SRF)   */
+    bool rr_dead;           /* Russian roulette ended the sample here: no bounce, and no refraction / reflection either */
 };
 
 /*
@@ -90,7 +91,8 @@ template <bool COUNT, bool DIVK, bool PT = false>
 __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, const Ray &r, const Hit &h,
                                       Shaded &o, Counters &cnt, u32 *rng = nullptr, int depth_left = 0, int pt_stage = 0)
 {
-    /* pt_stage (PT only): 0 everything in one call (the statistical path tracer); 1 up to the bounce sampling; 2 only the
+    /* pt_stage (PT only): 3 = 2 for a sample the roulette of stage 1 ended (Shaded::rr_dead);
+     * 0 everything in one call (the statistical path tracer); 1 up to the bounce sampling; 2 only the
      * transparency / reflection part -- the eager path tracer calls the two stages around the bounce's subtree, because
      * the Fresnel split draws its number after that subtree has drawn its own (tracer.cpp: 2339-2703 before 3428-3466) */
     /* per-lane (divergent) material data: vector loads at byte offsets from the blob base; everything
@@ -217,6 +219,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
     }
 
     o.want_pt = false; o.pdir = {0, 0, 0}; o.ptw = {0, 0, 0}; o.lst_pt = 0; o.ptex = {0, 0, 0}; o.pldff = 0.0f;
+    o.rr_dead = PT && pt_stage == 3;
     if constexpr (PT)
     {
         /* path tracer, tracer.cpp:2339-2690: no light loop; the local colour is the material's emission, a diffuse
@@ -227,13 +230,16 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         {
             const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
             V3 t3 = tex;
-            bool go = (props & QR_PROP_DIFFUSE) != 0 && pt_stage != 2;
+            bool go = (props & QR_PROP_DIFFUSE) != 0 && pt_stage < 2;
             if (go && depth_left <= QR_MAX_DEPTH - 5)
             {
                 /* Russian roulette from the sixth level on: survive with the largest colour component */
                 float p = tex.x > tex.y ? tex.x : tex.y; p = p > tex.z ? p : tex.z;
                 const float u = pt_random(*rng);
                 go = u < p;
+                /* the survivors' mask stays the lane mask of the transparency and reflection blocks too (ctx_F_PRB,
+                 * tracer.cpp:2364-2366, 3193-3198): a sample the roulette ends spawns no child of any kind */
+                o.rr_dead = !go;
                 const float ip = 1.0f / p;
                 t3.x = tex.x * ip; t3.y = tex.y * ip; t3.z = tex.z * ip;
             }
@@ -427,13 +433,22 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
     o.want_tr = false; o.want_rf = false;
     o.lst_tr = 0; o.lst_rf = 0;
 
-    if (act && pt_stage != 1)
+    if (act && pt_stage != 1 && o.rr_dead)
+    {
+        /* TR_end -> TR_mix with nothing added (3556-3583), reflections skipped (M_RFL empty, 3615-3617) */
+        const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
+        float x0 = 1.0f - mt->c_trn;
+        x0 = x0 - mt->c_rfl;
+        o.x0 = cle(0.0f, x0) ? x0 : 0.0f;
+    }
+    else if (act && pt_stage != 1)
     {
         const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
         const float m_trn_c = mt->c_trn, m_rfl_c = mt->c_rfl;
         float c_trn = m_trn_c, c_rfl = m_rfl_c;
         float x0 = 0.0f, x1, x2, x3, x4 = 0.0f, x5, x6 = 0.0f, x7 = 0.0f;
         bool m_trn = true;
+        bool total_refl = false;
 
         /* transparency 3185-3552 */
         if (!(props & QR_PROP_OPAQUE))
@@ -465,6 +480,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
                         c_trn = 0.0f;
                         c_rfl = m_rfl_c + m_trn_c;
                         tir = true;
+                        total_refl = true;
                     }
                 }
                 if (!tir)
@@ -510,7 +526,8 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         {
             /* path tracer, 3428-3466: from the third level on a Fresnel surface follows ONE of the two children, the
              * reflection with probability P = 0.25 + 0.5 c_rfl / (c_trn + c_rfl), weights divided by the probabilities */
-            if (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL) && depth_left <= QR_MAX_DEPTH - 2)
+            /* total inner reflection leaves through TR_tir -> TR_end (3279-3295) before the split: no number drawn */
+            if (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL) && depth_left <= QR_MAX_DEPTH - 2 && !total_refl)
             {
                 const float u = pt_random(*rng);
                 const float P = 0.25f + 0.5f * (c_rfl / (c_trn + c_rfl));

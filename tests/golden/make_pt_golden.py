@@ -33,10 +33,16 @@ with tempfile.TemporaryDirectory() as tmp:
         print(name)
     # the reference's first TWO frames at recursion depths 2 and 8, and its first frame at the default depth 10: the eager
     # path tracer (Scene.set_pt(True, eager=True)) follows the reference's shading order and must reproduce them
-    for d, n in ((2, 2), (6, 2), (8, 1), (8, 2), (10, 1)):
+    for d, n in ((2, 2), (6, 2), (8, 1), (8, 2), (10, 1), (10, 2), (10, 4)):
         raw = os.path.join(tmp, "f.raw")
         subprocess.run([REF, "--scene", "test18", "-w", "160", "-h", "120", "--depth", str(d), "--pt", str(n), "--out", raw],
                        check=True, cwd=tmp, stdout=subprocess.DEVNULL)
         with open(raw, "rb") as f, open(os.path.join(OUT, f"test18_160_pt_d{d}_n{n}.raw.gz"), "wb") as g:
             g.write(gzip.compress(f.read(), 9, mtime=0))
         print("eager", d, n)
+    # the same with 4x FSAA, Gamma and Fresnel (the split of Fresnel surfaces draws numbers too): first three frames
+    raw = os.path.join(tmp, "f.raw")
+    subprocess.run([REF, "--scene", "test18", "-w", "160", "-h", "120", "--fsaa", "4", "--gamma", "--fresnel", "--pt", "3", "--out", raw],
+                   check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+    with open(raw, "rb") as f, open(os.path.join(OUT, "test18_160_gf_aa4_pt_n3.raw.gz"), "wb") as g:
+        g.write(gzip.compress(f.read(), 9, mtime=0))

@@ -1,18 +1,17 @@
 """Path-tracer mode (the reference's RT_FEAT_PT).
 
-PARITY UNPINNED.  The reference shades eagerly: every hit that passes the depth test while a list is walked is shaded
-at once, and in path-tracer mode that shading draws random numbers, so its stream of numbers depends on an order the
-deferred-shading backend does not have.  The backend uses the same generator, the same per-sample seeds
-(rt_Scene::reset_pseed), the same sampling formulas (tent-filter jitter, cosine hemisphere with the reference's power
-series, Russian roulette, Fresnel split) and the same running-mean accumulation, so its frames have the reference's
-DISTRIBUTION: these tests compare statistics of N accumulated frames with frames of the reference itself
-(tests/golden/pt/, made by tests/golden/make_pt_golden.py from oracle/_ref with the smallpt Cornell box, test18).
-The oracle has no path tracer: it is not involved here.
+Two modes, both against frames of the reference itself (tests/golden/pt/, made by tests/golden/make_pt_golden.py from
+oracle/_ref with the smallpt Cornell box, test18; the oracle has no path tracer and is not involved):
 
-What IS pinned bit-exactly: the first frame at recursion depth 0.  There the colour of a pixel is the emission of the
-surface its jittered primary ray meets, and the jitter uses the first two numbers of the sample's stream, before any
-shading: seeding, generator, jitter arithmetic, emission, accumulation and packing must reproduce the reference's frame
-pixel for pixel (test_gpu_path_tracer_first_frame_depth0_is_bit_exact).
+* EAGER (set_pt(True, eager=True)): PINNED, bit-exact.  The reference shades eagerly -- every hit that passes the depth
+  test while a list is walked is shaded at once, and in path-tracer mode that shading draws random numbers -- so a
+  sample's stream depends on that order.  The eager machine (csrc/qr_pt_eager.hpp) follows it and reproduces the
+  reference's frames pixel for pixel: recursion depths 0..10, 1 to 512 accumulated frames, 4x FSAA, Gamma, Fresnel.
+* STATISTICAL (set_pt(True)): the fast kernel with deferred shading: same generator, per-sample seeds
+  (rt_Scene::reset_pseed), sampling formulas (tent-filter jitter, cosine hemisphere with the reference's power series,
+  Russian roulette, Fresnel split) and running-mean accumulation, numbers drawn for the final hit of a walk only.  Its
+  frames have the reference's DISTRIBUTION: statistics of N accumulated frames are compared; its first frame at
+  recursion depth 0, where no shading order exists, is the reference's pixel for pixel.
 """
 import gzip
 import os
@@ -142,15 +141,12 @@ def test_gpu_path_tracer_first_frame_depth0_is_bit_exact(qr, ref, fsaa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth,frames,allowed", [(2, 2, 0), (6, 2, 0), (8, 1, 0), (8, 2, 4), (10, 1, 10)])
+@pytest.mark.parametrize("depth,frames,allowed", [(2, 2, 0), (6, 2, 0), (8, 1, 0), (8, 2, 0), (10, 1, 0), (10, 2, 0), (10, 4, 0)])
 def test_gpu_eager_path_tracer_reproduces_the_references_frames(qr, depth, frames, allowed):
     """set_pt(True, eager=True): shading in the reference's order (csrc/qr_pt_eager.hpp) -- every hit that passes the
     depth test is shaded at once, bounce subtree first, then the Fresnel split, refraction, reflection -- so a sample
-    consumes the reference's numbers.  Pixel for pixel the reference's: frame 1 up to recursion depth 8, frames 1 AND 2
-    (the second frame's jitter depends on every number the first one drew) up to depth 6.  Beyond that a few samples in
-    ten thousand -- paths of seven and more bounces -- part from the reference for a reason not found this round
-    (DESIGN.md 8): measured 1 differing pixel of 19 200 in the second frame at depth 8, 3 in the first at depth 10; the
-    reference itself gives the same frames on its 128-, 256- and 512-bit targets, so the deviation is ours."""
+    consumes the reference's numbers.  Pixel for pixel the reference's frames (qr_ref --pt N) at every recursion depth up
+    to the default 10, first frame and accumulated ones (frame k's jitter depends on every number frames 1..k-1 drew)."""
     import torch
     scn = qr.Scene(_blob("test18_160_pt"))
     scn.set_depth(depth)
@@ -161,6 +157,37 @@ def test_gpu_eager_path_tracer_reproduces_the_references_frames(qr, depth, frame
     torch.cuda.synchronize()
     want = _ref("test18_160_pt_d%d_n%d" % (depth, frames), scn.width, scn.height)
     assert int((f.cpu().numpy().view(np.uint32) != want).sum()) <= allowed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", [64, 512])
+def test_gpu_eager_path_tracer_accumulates_the_references_image(qr, frames):
+    """N accumulated frames at the default depth: every one of the N x 19 200 streams stays the reference's to the end."""
+    import torch
+    scn = qr.Scene(_blob("test18_160_pt"))
+    scn.set_pt(True, eager=True)
+    f = scn.new_frame()
+    for _ in range(frames):
+        scn.render(f)
+    torch.cuda.synchronize()
+    want = _ref("test18_160_pt_n%d" % frames, scn.width, scn.height)
+    assert int((f.cpu().numpy().view(np.uint32) != want).sum()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_eager_path_tracer_with_fsaa_gamma_fresnel(qr):
+    """4x FSAA (four samples per pixel, each with its own stream), Gamma, Fresnel (the split of Fresnel surfaces between
+    reflection and refraction draws numbers): the reference's first three accumulated frames, pixel for pixel."""
+    import torch
+    scn = qr.Scene(_blob("test18_160_gf_aa4_pt"))
+    scn.set_pt(True, eager=True)
+    f = scn.new_frame()
+    for _ in range(3):
+        scn.render(f)
+    torch.cuda.synchronize()
+    want = _ref("test18_160_gf_aa4_pt_n3", scn.width, scn.height)
+    assert int((want != 0).sum()) > 1000
+    assert int((f.cpu().numpy().view(np.uint32) != want).sum()) == 0
 
 
 @pytest.mark.gpu
