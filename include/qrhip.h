@@ -165,8 +165,7 @@ int qr_scene_set_depth(qr_device_scene *scn, int depth);
  * rt_Scene::set_pton, engine.cpp:3729).  on != 0 (re)starts the accumulation: per pixel sample one LCG24 state,
  * seeded like rt_Scene::reset_pseed, and three colour planes on the device.  Every qr_render_async then adds ONE sample
  * per pixel sample and writes the running mean as the frame.  on == 2: shade in the reference's (eager) order, which
- * reproduces the reference's frames pixel for pixel (every depth, any number of accumulated frames; slow;
- * scenes without custom clippers).  on == 1: the fast kernel with deferred shading: statistically equivalent to the
+ * reproduces the reference's frames pixel for pixel (every depth, any number of accumulated frames; slow).  on == 1: the fast kernel with deferred shading: statistically equivalent to the
  * reference, not bit-exact: the reference's stream of random numbers depends on its eager shading order.
  * Rendered by a packet-walk kernel instance of its own; ids / counting renders are refused in this mode; qr_render0
  * (drop-in) refuses inf_PT_ON because the engine's planes live on the host.

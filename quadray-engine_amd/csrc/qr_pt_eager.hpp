@@ -145,7 +145,7 @@ __device__ __forceinline__ V3 pt_eager(const Ctx &cx, const Ray &primary, bool i
                     SurfS s;
                     ld_surf_lane(B, p_srf, s);
                     const float tb = w.tbuf;
-                    solve_cell<false, true>(B, p_op, p_srf, s, cur, dd, w, h);
+                    solve_cell<false, true, false, true>(B, p_op, p_srf, s, cur, dd, w, h);     /* with the cell's clipper program, per lane */
                     p_op = 0;
                     if (w.tbuf != tb) mode = M_SHADE1;      /* accepted: shaded before the walk goes on */
                 }

@@ -147,7 +147,7 @@ __device__ __forceinline__ lm_t clip_box(lm_t m, float tbuf, float tmin, float t
 /* CC_clp, tracer.cpp:1597-2160.  Returns the lanes of `m` whose hit at `t`  */
 /* survives; `loc` is the local hit (ctx_NEW_* of the surface's space).      */
 /* ------------------------------------------------------------------------ */
-template <bool DIV>
+template <bool DIV, bool CLIPL = false>
 __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32 op, const Ray &r, float tbuf,
                                                     const ClipIn<DIV> &ci, float t, int side, typename MK<DIV>::T m, V3 &loc)
 {
@@ -242,24 +242,27 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
     }
     else m = clip_box(m, tbuf, r.tmin, t, x4, x5, x6, s);
 
-    /* custom clipping, 1931-2151: the surface's clipper program (wave-uniform cells only: the per-lane walk
-     * hands cells with clippers to the uniform path one at a time) */
-    if constexpr (!DIV) if ((op & QR_OPF_CLIP) && m != 0)
+    /* custom clipping, 1931-2151: the surface's clipper program.  Wave-uniform cells run it on scalar loads; the
+     * per-lane walks never meet one (lists with clippers are not flagged for them, qr_compile.cpp) except the eager
+     * path tracer's (CLIPL), where every lane runs the program of ITS cell */
+    bool run_clip;
+    if constexpr (DIV) run_clip = (op & QR_OPF_CLIP) && m; else run_clip = (op & QR_OPF_CLIP) && m != 0;
+    if constexpr (!DIV || CLIPL) if (run_clip)
     {
-        lm_t c_acc = 0;
+        typename K::T c_acc = K::none();
         V3 cxyz = {0.0f, 0.0f, 0.0f};                   /* the hit in the cached clipper trnode's space */
         u32 cp = s.clip;
         for (;;)
         {
-            cp = __builtin_amdgcn_readfirstlane(cp);
+            if constexpr (!DIV) cp = __builtin_amdgcn_readfirstlane(cp);
             const u32x2 cc = *(const QR_CONST u32x2 *)(B + cp);
             cp += 16;
             const u32 cop = cc.x;
             if (cop == 0) break;
             if (cop & (QR_CLT_ENTER | QR_CLT_LEAVE))
             {
-                if (cop & QR_CLT_ENTER) { c_acc = m; m = (cop & QR_CLF_CDEF) ? ~0ull : 0ull; }
-                else m = ~m & c_acc;
+                if (cop & QR_CLT_ENTER) { c_acc = m; m = (cop & QR_CLF_CDEF) ? K::inv(K::none()) : K::none(); }
+                else m = K::inv(m) & c_acc;
                 continue;
             }
             const u32 koff = cc.y;
@@ -312,7 +315,7 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
                 }
                 f4 = f4 - ks3; f4 = f4 + f5; f4 = f4 + f6;
             }
-            m &= (cop & QR_CLF_INNER) ? LM(cge(f4, 0.0f)) : LM(cle(f4, 0.0f));
+            m = m & ((cop & QR_CLF_INNER) ? K::of(cge(f4, 0.0f)) : K::of(cle(f4, 0.0f)));
         }
     }
     return m;
@@ -374,7 +377,7 @@ __device__ __forceinline__ void cell_space(BaseP B, u32 op, u32 srf_off, float p
     }
 }
 
-template <bool SHADOW, bool DIV, bool WORLD = false>
+template <bool SHADOW, bool DIV, bool WORLD = false, bool CLIPL = false>
 __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const SurfS &s, const Ray &r,
                                            float dd, WalkState &w, Hit &h)
 {
@@ -546,7 +549,7 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
             mask_t m = (p == 0 ? cm0 : cm1) & K::inv(done);
             if (!K::any(m)) continue;
             V3 loc;
-            m = clip<DIV>(B, s, op, r, w.tbuf, ci, t, side, m, loc);
+            m = clip<DIV, CLIPL>(B, s, op, r, w.tbuf, ci, t, side, m, loc);
             done = done | m;
             if (K::lane(m))
             {

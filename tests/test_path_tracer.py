@@ -191,11 +191,13 @@ def test_gpu_eager_path_tracer_with_fsaa_gamma_fresnel(qr):
 
 
 @pytest.mark.gpu
-def test_gpu_eager_machine_with_ray_tracer_shading_is_the_ray_tracer(qr):
+@pytest.mark.parametrize("name", ["test18_160", "demo01_160", "demo02_160", "demo03_160", "test09_160", "test13_160", "test16_160"])
+def test_gpu_eager_machine_with_ray_tracer_shading_is_the_ray_tracer(qr, name):
     """Self-test of the eager machine: with the ray tracer's shading (lights, shadows, no random numbers) shading every
-    provisional hit cannot change a pixel, so its frame is the deferred kernel's, at every depth."""
+    provisional hit cannot change a pixel, so its frame is the deferred kernel's, at every depth -- also on the scenes
+    whose surfaces carry clipper programs (CSG), which the machine's walk runs per lane."""
     import torch
-    blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "test18_160.qrs.gz"), "rb").read())
+    blob = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", name + ".qrs.gz"), "rb").read())
     scn = qr.Scene(blob)
     for depth in (10, 3, 0):
         scn.set_depth(depth)
