@@ -29,7 +29,7 @@ typedef enum qr_status
     QR_OK            =  0,
     QR_ERR_ARG       = -1,  /* bad argument / malformed snapshot            */
     QR_ERR_ABI       = -2,  /* unsupported reference build configuration    */
-    QR_ERR_UNSUP     = -3,  /* outside what this entry point does (e.g. inf_PT_ON through qr_render0, 8x FSAA) */
+    QR_ERR_UNSUP     = -3,  /* outside what this entry point does (e.g. 8x FSAA, counting renders in path-tracer mode) */
     QR_ERR_DEVICE    = -4,  /* no usable HIP device / HIP runtime error     */
     QR_ERR_IO        = -5,
     QR_ERR_NOMEM     = -6
@@ -65,6 +65,9 @@ typedef struct qr_abi_desc
  * index, index+thnum, ... of the frame on the current HIP device and writes
  * 0x00RRGGBB pixels to s_inf->frame (host memory, stride frm_row).
  * Re-entrant; retains no pointer after returning.
+ * Path-tracer mode (s_inf->pt_on, tracer.h:214): as render0 does, the call advances the sample counter in s_inf
+ * (inf_PTS_C/_O/_U) and adds one sample to the engine's seed and colour planes (inf_PSEED, inf_PTR_R/G/B): its rows of
+ * those planes travel to the device and back; the frames are the reference's bit for bit.
  */
 int qr_render0(const void *s_inf, const qr_abi_desc *abi);
 
@@ -167,8 +170,8 @@ int qr_scene_set_depth(qr_device_scene *scn, int depth);
  * per pixel sample and writes the running mean as the frame.  on == 2: shade in the reference's (eager) order, which
  * reproduces the reference's frames pixel for pixel (every depth, any number of accumulated frames; slow).  on == 1: the fast kernel with deferred shading: statistically equivalent to the
  * reference, not bit-exact: the reference's stream of random numbers depends on its eager shading order.
- * Rendered by a packet-walk kernel instance of its own; ids / counting renders are refused in this mode; qr_render0
- * (drop-in) refuses inf_PT_ON because the engine's planes live on the host.
+ * Rendered by a packet-walk kernel instance of its own; ids / counting renders are refused in this mode.  qr_render0
+ * (drop-in) uses the engine's own planes and the eager kernel.
  */
 int qr_scene_set_pt(qr_device_scene *scn, int on);
 

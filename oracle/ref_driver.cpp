@@ -224,7 +224,7 @@ static void usage()
     fprintf(stderr,
         "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
         "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
-        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K]\n");
+        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim]\n");
 }
 
 
@@ -339,6 +339,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
+        else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }   /* every frame through ref_shim.cpp -> qr_render0 */
         else { usage(); return 2; }
     }
     if (scene_name == NULL) { usage(); return 2; }

@@ -718,6 +718,7 @@ struct DropIn
     std::vector<uint8_t> blob, last_blob;
     QrProgram prog;
     bool resident = false;              /* prog is the image in d_blob */
+    uint32_t *d_pt = nullptr; size_t pt_cap = 0;   /* path-tracer mode: device copies of the engine's seed plane and three colour planes */
 };
 static thread_local DropIn g_drop;
 
@@ -732,6 +733,7 @@ static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_b
         c.d_blob = nullptr; c.d_cap = 0; c.h_stage = nullptr; c.h_cap = 0;
         c.d_frame = nullptr; c.df_cap = 0; c.h_frame = nullptr; c.hf_cap = 0;
         c.resident = false;
+        c.d_pt = nullptr; c.pt_cap = 0;
         c.device = dev;
         HIP_TRY(hipStreamCreateWithFlags(&c.sk, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c.sc, hipStreamNonBlocking));
@@ -776,6 +778,74 @@ static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_b
     return QR_OK;
 }
 
+/*
+ * Path-tracer mode through the drop-in entry point.  The engine keeps one LCG state per pixel sample (inf_PSEED) and three
+ * colour planes with the running mean (inf_PTR_R/G/B, engine.cpp:2875-2893), all frm_row << fsaa words per row, and a
+ * sample counter in every thread's rt_SIMD_INFOX which render0 itself advances (tracer.cpp:1112-1136).  A call owns rows
+ * index, index + thnum, ...: those rows of the four planes travel to the device before the launches and back after them.
+ */
+struct DropInPt
+{
+    uint8_t *host[4] = { nullptr, nullptr, nullptr, nullptr };     /* seeds, r, g, b on the host */
+    size_t row_bytes = 0, plane_words = 0;
+    int first = 0, step = 1, rows = 0;
+};
+
+static int dropin_pt_begin(DropIn &c, const void *s_inf, const qr_abi_desc *abi, const qr_frame &fr, DropInPt &io, PtParams &pt)
+{
+    uint8_t *inf = (uint8_t *)(uintptr_t)s_inf;         /* the counter below is the one field of s_inf render0 writes */
+    const size_t ps = abi->pointer_bits / 8, Q = abi->quads, P = abi->pointer_bits / 32;
+    const size_t ib = Q * 0x100;
+    static const int slot[4] = { 3, 16, 17, 18 };       /* inf_PSEED, inf_PTR_R, inf_PTR_G, inf_PTR_B (tracer.h:163, 205-211) */
+    for (int k = 0; k < 4; k++)
+    {
+        uint64_t p = 0;
+        if (ps == 8) memcpy(&p, inf + ib + (size_t)slot[k] * ps, 8); else { uint32_t a; memcpy(&a, inf + ib + (size_t)slot[k] * ps, 4); p = a; }
+        if (p == 0) return qr_fail(QR_ERR_ARG, "path-tracer mode without seed / colour planes in s_inf");
+        io.host[k] = (uint8_t *)(uintptr_t)p;
+    }
+    /* sample count + 1, weights of the running mean: inf_PTS_C / _O / _U, lane-broadcast (tracer.h:251-257) */
+    float *pts_c = (float *)(inf + Q * 0x130 + 0x100 * P), *pts_o = (float *)(inf + Q * 0x140 + 0x100 * P),
+          *pts_u = (float *)(inf + Q * 0x150 + 0x100 * P);
+    const float cnt = pts_c[0] + 1.0f, o = 1.0f / cnt, u = 1.0f - o;
+    for (size_t l = 0; l < Q * 4; l++) { pts_c[l] = cnt; pts_o[l] = o; pts_u[l] = u; }
+
+    const size_t ns = (size_t)1 << fr.fsaa;
+    io.row_bytes = (size_t)fr.frm_row * ns * 4;
+    io.plane_words = (size_t)fr.frm_row * fr.frm_h * ns;
+    io.step = fr.thnum > 0 ? fr.thnum : 1;
+    io.first = fr.index;
+    io.rows = fr.frm_h > io.first ? (fr.frm_h - io.first + io.step - 1) / io.step : 0;
+    if (c.pt_cap < 4 * io.plane_words)
+    {
+        if (c.d_pt) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c.d_pt); }
+        c.d_pt = nullptr; c.pt_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c.d_pt, 4 * io.plane_words * 4));
+        c.pt_cap = 4 * io.plane_words;
+    }
+    for (int k = 0; k < 4 && io.rows > 0; k++)
+        HIP_TRY(hipMemcpy2DAsync((uint8_t *)(c.d_pt + (size_t)k * io.plane_words) + (size_t)io.first * io.row_bytes, io.step * io.row_bytes,
+                                 io.host[k] + (size_t)io.first * io.row_bytes, io.step * io.row_bytes,
+                                 io.row_bytes, (size_t)io.rows, hipMemcpyHostToDevice, c.sk));
+    pt.seeds = c.d_pt;
+    pt.acc_r = (float *)(c.d_pt + io.plane_words); pt.acc_g = (float *)(c.d_pt + 2 * io.plane_words); pt.acc_b = (float *)(c.d_pt + 3 * io.plane_words);
+    pt.pts_o = o; pt.pts_u = u;
+    pt.eager = 1;               /* the reference's shading order: its random streams, its frames */
+    pt.pad = 0;
+    return QR_OK;
+}
+
+static hipError_t dropin_pt_end(DropIn &c, const DropInPt &io)
+{
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 4 && io.rows > 0 && e == hipSuccess; k++)
+        e = hipMemcpy2DAsync(io.host[k] + (size_t)io.first * io.row_bytes, io.step * io.row_bytes,
+                             (const uint8_t *)(c.d_pt + (size_t)k * io.plane_words) + (size_t)io.first * io.row_bytes, io.step * io.row_bytes,
+                             io.row_bytes, (size_t)io.rows, hipMemcpyDeviceToHost, c.sk);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.sk);
+    return e;
+}
+
 extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
 {
     const bool verbose = getenv("QR_VERBOSE") != nullptr;
@@ -784,12 +854,6 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     std::string err;
     int rc = qr_flatten_impl(s_inf, abi, c.blob, err);
     if (rc != QR_OK) return qr_fail(rc, err);
-    if (c.blob.size() >= sizeof(qr_header))
-    {
-        const qr_header *hh = (const qr_header *)c.blob.data();
-        if ((size_t)hh->off_frame + sizeof(qr_frame) <= c.blob.size() && ((const qr_frame *)(c.blob.data() + hh->off_frame))->pt_on)
-            return qr_fail(QR_ERR_UNSUP, "path-tracer mode (inf_PT_ON): the engine's colour and seed planes live on the host; use the snapshot API (qr_scene_set_pt)");
-    }
     const double t1 = now_ms();
 
     /* frame pointer and stride: inf_FRAME / inf_FRM_ROW, tracer.h:186-190 */
@@ -841,6 +905,13 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     }
     const double t3 = now_ms();
 
+    DropInPt ptio; PtParams pt = {};
+    if (fr.pt_on)
+    {
+        rc = dropin_pt_begin(c, s_inf, abi, fr, ptio, pt);
+        if (rc != QR_OK) return rc;
+    }
+
     LaunchP lp = {};
     lp.B = (const char *)c.d_blob;
     lp.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
@@ -858,7 +929,10 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         lp.row_begin = (int32_t)c.prog.block_row[k]; lp.row_end = (int32_t)c.prog.block_row[k + 1];
         if (lp.n_blocks > 0)
         {
-            if (c.prog.has_long_lists || c.prog.has_grids)
+            if (fr.pt_on)
+                hipLaunchKernelGGL(qr_render_pt_kernel, dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                                   lp, pt, (uint32_t *)c.d_frame, c.d_counters);
+            else if (c.prog.has_long_lists || c.prog.has_grids)
                 hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
             else
@@ -873,6 +947,7 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         if (e == hipSuccess && n > 0) e = hipMemcpyAsync(c.h_frame + off, (const uint32_t *)c.d_frame + off, n, hipMemcpyDeviceToHost, c.sc);
         if (e == hipSuccess) e = hipEventRecord(c.ev_c[k], c.sc);
     }
+    if (fr.pt_on && e == hipSuccess) e = dropin_pt_end(c, ptio);    /* the planes with this frame's sample go back to the engine */
     const double t4 = now_ms();
     /* the host moves finished blocks into the caller's frame: only the rows this call owns (index / thnum),
      * honouring a negative stride (bottom-up frames, engine.cpp:2814-2850) */

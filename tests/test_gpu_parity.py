@@ -118,6 +118,34 @@ def test_gpu_drop_in_through_reference_engine():
         assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
 
 
+@pytest.mark.parametrize("args", [["-w", "160", "-h", "120", "--pt", "3"],
+                                  ["-w", "200", "-h", "150", "--pt", "4", "--fsaa", "4", "--gamma", "--fresnel"],
+                                  ["-w", "160", "-h", "120", "--pt", "3", "--threads", "4"],
+                                  ["-w", "96", "-h", "64", "--pt", "2", "--depth", "4"]])
+def test_gpu_drop_in_path_tracer_through_reference_engine(args):
+    """Path-tracer mode through the drop-in boundary: the unmodified engine accumulates N frames with its own CPU SIMD
+    backend in one process and, in another, with EVERY frame going through ref_shim.cpp -> qr_render0 (--shim): the
+    engine's seed and colour planes travel to the GPU and back each frame, the eager path-tracer kernel draws the
+    reference's numbers.  The N-th frames must be equal (the driver prints the frame hash)."""
+    import os
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/qr_ref_shim was not built (needs /root/reference at build time)")
+    tmp = tempfile.mkdtemp(prefix="qrdroppt_")
+    os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
+    hashes = []
+    for extra in ([], ["--shim"]):
+        out = subprocess.run([exe, "--scene", "test18"] + args + extra, cwd=tmp, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        hashes.append([l.split()[1] for l in out.stdout.splitlines() if l.startswith("hash ")][0])
+        if extra:
+            assert "simd 128x1v8" in out.stdout, out.stdout       # the shim's target was the one rendering
+    assert hashes[0] == hashes[1], hashes
+
+
 @pytest.mark.parametrize("mode", [[], ["--gather"]])
 def test_gpu_two_rank_bench_path_on_one_gpu(mode):
     """The N = 2 code path of bench.py -- MultiRender (one multi-target launch per step), the buffer rotation and
