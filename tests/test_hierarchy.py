@@ -175,3 +175,24 @@ def test_updates_outside_the_scope_are_refused(qr):
     bad[k]["srf"] = 100000
     with pytest.raises(qr.QrError, match="out of range"):
         qr.hierarchy_apply(load_blob("test13_160"), bad, tb["opts"])
+
+
+@pytest.mark.parametrize("name", ["demo01_160_aa2_t2500", "test13_160", "test16_160_noopt"])
+def test_tree_dump_through_the_engine_reproduces_the_fixture(name, tmp_path):
+    """The fixture generator's path -- the unmodified engine renders, the shim captures the snapshot, qr_capture_index maps
+    the engine's records to snapshot indices, ref_driver dumps the tree -- gives the committed tree again (needs
+    oracle/_ref, which exists in the build container and travels to the GPU box)."""
+    import subprocess
+    from conftest import ROOT
+    shim = os.path.join(ROOT, "oracle", "_ref", "qr_ref_shim")
+    if not os.path.exists(shim):
+        pytest.skip("oracle/_ref/qr_ref_shim is not built")
+    m = MANIFEST[name]
+    (tmp_path / "dump").mkdir()
+    out, snap = tmp_path / "t.json", tmp_path / "s.qrs"
+    cmd = [shim, "--scene", m["scene"], "-w", str(m["w"]), "-h", str(m["h"]), "--snapshot", str(snap), "--tree", str(out)] + m["args"]
+    subprocess.run(cmd, cwd=tmp_path, check=True, capture_output=True, timeout=120)
+    with open(os.path.join(TREE, name + ".json.gz"), "rb") as f:
+        want = json.loads(gzip.decompress(f.read()))
+    assert json.loads(out.read_text()) == want
+    assert snap.read_bytes() == load_blob(name)
