@@ -44,7 +44,18 @@ idx = np.argsort(-dur)[:8]
 for i in idx:
     print(f"  slow wave: {dur[i]:7.1f} us start {st[i]:6.1f}  non-shadow walks {int(w[i,7])} cells {int(w[i,5])}  shadow walks {int(w[i,6])} cells {int(w[i,4])}"
           f"  -> {dur[i]*1e3/max(1,int(w[i,4])+int(w[i,5])):.0f} ns per cell; us in traverse {int(w[i,8])/100:.1f}, shade {int(w[i,9])/100:.1f} of which shadow walks {int(w[i,10])/100:.1f}")
-tot_cells = w[:, 4].astype(np.int64) + w[:, 5].astype(np.int64)
+# where the slowest waves are: footprint coordinates (schedule entry), and what their pixels see (primary hit ids)
+ids = torch.zeros((scn.height, scn.width), dtype=torch.int32, device="cuda")
+scn.render(f, ids=ids); torch.cuda.synchronize()
+idn = ids.cpu().numpy()
+fw, fh = (8, 8) if scn.info.fsaa == 0 else ((8, 4) if scn.info.fsaa == 1 else (4, 4))
+for i in idx:
+    o = int(w[i, 4]); bx, by = o & 0x3FFF, (o >> 14) & 0x3FFF
+    tile = idn[by * fh:(by + 1) * fh, bx * fw:(bx + 1) * fw]
+    u, c = np.unique(tile, return_counts=True)
+    print(f"  list groups walked: nearest-hit {int(w[i,5])} shadow {int(w[i,6])} in {int(w[i,7])} rounds;", end="")
+    print(f"  slow wave at pixels x {bx*fw}..{bx*fw+fw-1} y {by*fh}..{by*fh+fh-1} heavy {o >> 30}: primary hits (surface*2+side: count) " + " ".join(f"{a}:{b}" for a, b in zip(u, c)))
+tot_cells = w[:, 4].astype(np.int64) * 0 + w[:, 5].astype(np.int64)
 print(f"all waves: cells per wave mean {tot_cells.mean():.1f}; sum of wave durations / sum of cells = {dur.sum()*1e3/max(1,tot_cells.sum()):.0f} ns per cell")
 # occupancy over time: waves in flight sampled every 5% of the kernel
 T = en.max()
