@@ -1442,6 +1442,9 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
  * DIVK = false is the kernel instance for scenes without long hierarchies (every scene the reference engine
  * prepares): the per-lane walk is compiled out there, which is worth 4 % of instructions through register pressure.
  */
+#ifdef QR_WAVETIME
+__shared__ unsigned qr_wt_groups[2];    /* list groups walked by this wave: nearest-hit, shadow (tools/gpu_wavetime.py) */
+#endif
 template <bool SHADOW, bool DIVK>
 __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS
@@ -1457,6 +1460,9 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         const int leader = __ffsll((long long)pending) - 1;
         const u32 head = (u32)__builtin_amdgcn_readlane((int)r.list, leader);
         const lm_t mine = pending & LM(r.list == head);
+#ifdef QR_WAVETIME
+        if ((int)(threadIdx.x & 63u) == leader) qr_wt_groups[SHADOW ? 1 : 0]++;
+#endif
         if constexpr (DIVK)
         {
         const int n_left = __popcll(pending), n_mine = __popcll(mine);
