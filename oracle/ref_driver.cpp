@@ -310,6 +310,40 @@ static bool dump_tree(rt_Scene *sc, const char *scene, long time_ms, const char 
     return true;
 }
 
+/*
+ * --jitter SEED: before the engine sees the scene, every object of its static description gets another transform --
+ * right-angle and arbitrary rotations, unit, negative and non-unit scalers, shifted positions -- so that the hierarchical
+ * update meets combinations the stock scenes do not have (fixtures tests/golden/tree/fuzz_*; the frame is not kept).
+ */
+static uint64_t g_jit = 0;
+static uint32_t jit_next() { g_jit ^= g_jit << 13; g_jit ^= g_jit >> 7; g_jit ^= g_jit << 17; return (uint32_t)(g_jit >> 11); }
+static void jitter_tree(rt_OBJECT *arr, int n, int level)
+{
+    static const rt_real right[] = { -270.0f, -180.0f, -90.0f, 0.0f, 90.0f, 180.0f, 270.0f };
+    static const rt_real scales[] = { 0.5f, 2.0f, 1.5f, -2.0f, -1.0f, 1.25f };
+    for (int i = 0; i < n; i++)
+    {
+        rt_OBJECT *o = &arr[i];
+        const bool cam = o->obj.tag == RT_TAG_CAMERA;
+        const uint32_t mode = jit_next() % 10;
+        for (int a = 0; a < 3 && !cam; a++)
+        {
+            if (mode < 5) o->trm.rot[a] = right[jit_next() % 7];                               /* stays trivial */
+            else if (mode < 8) o->trm.rot[a] = (rt_real)((int)(jit_next() % 3600) - 1800) / 10.0f;
+            /* else: as the scene has it */
+        }
+        const uint32_t sm = jit_next() % 10;
+        for (int a = 0; a < 3 && !cam; a++)
+        {
+            if (sm == 0) o->trm.scl[a] = -1.0f;
+            else if (sm < 3) o->trm.scl[a] = scales[jit_next() % 6];
+            else if (sm < 5) o->trm.scl[a] = 1.0f;
+        }
+        for (int a = 0; a < 3; a++) o->trm.pos[a] += (rt_real)((int)(jit_next() % 401) - 200) / 100.0f;
+        if (o->obj.tag == RT_TAG_ARRAY && level < 16) jitter_tree((rt_OBJECT *)o->obj.pobj, o->obj.obj_num, level + 1);
+    }
+}
+
 int main(int argc, char **argv)
 {
     int pt_frames = 0;
@@ -339,13 +373,15 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
-        else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }   /* every frame through ref_shim.cpp -> qr_render0 */
+        else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }
+        else if (!strcmp(argv[i], "--jitter") && i + 1 < argc) g_jit = 0x9E3779B97F4A7C15ull * (uint64_t)(atol(argv[++i]) + 1);   /* every frame through ref_shim.cpp -> qr_render0 */
         else { usage(); return 2; }
     }
     if (scene_name == NULL) { usage(); return 2; }
     rt_SCENE *scn = find_scene(scene_name);
     if (scn == NULL) { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
     if (g_threads < 1) g_threads = 1;
+    if (g_jit != 0 && scn->root.tag == RT_TAG_ARRAY) jitter_tree((rt_OBJECT *)scn->root.pobj, scn->root.obj_num, 0);
 
     int rc = 0;
     try

@@ -27,6 +27,13 @@ EXTRA = {
 }
 
 
+# fuzzed transforms (oracle/ref_driver.cpp --jitter SEED: right-angle and arbitrary rotations, negative and non-unit scalers,
+# shifted positions on every object of the scene's static description): tree + the snapshot of that run with its texels
+# zeroed (the hierarchy tests do not look at them; 160 KB of texture would travel with every case otherwise)
+FUZZ = [("test14", 1, []), ("test14", 2, []), ("test14", 3, ["--opts", "none"]), ("test14", 4, []),
+        ("test13", 1, []), ("test16", 1, []), ("demo02", 1, []), ("test12", 1, ["--opts", "none"]), ("test09", 5, [])]
+
+
 def run(scene, w, h, args, tmp):
     raw, qrs, tree = (os.path.join(tmp, n) for n in ("f.raw", "s.qrs", "t.json"))
     cmd = [REF, "--scene", scene, "-w", str(w), "-h", str(h), "--out", raw, "--snapshot", qrs, "--tree", tree] + args
@@ -62,5 +69,25 @@ def main():
         print(name, "frame + tree")
 
 
+def fuzz():
+    import struct
+    for scene, seed, args in FUZZ:
+        tmp = tempfile.mkdtemp(prefix="qrtree_")
+        _, blob, tree = run(scene, 32, 24, ["--jitter", str(seed)] + args, tmp)
+        b = bytearray(blob)
+        n_texels, off_texels = struct.unpack_from("<I", b, 4 * 9)[0], struct.unpack_from("<I", b, 4 * 16)[0]
+        b[off_texels:off_texels + 4 * n_texels] = bytes(4 * n_texels)
+        name = "fuzz_%s_s%d%s" % (scene, seed, "_noopt" if args else "")
+        with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
+            f.write(gzip.compress(tree, 9, mtime=0))
+        with open(os.path.join(OUT, name + ".qrs.gz"), "wb") as f:
+            f.write(gzip.compress(bytes(b), 9, mtime=0))
+        print(name)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["fuzz"]:
+        fuzz()
+    else:
+        main()
+        fuzz()
