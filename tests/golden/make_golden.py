@@ -56,6 +56,14 @@ case("test07_160_gf", "test07", 160, 120, ["--gamma", "--fresnel"])
 case("test13_160_gf_aa4", "test13", 160, 120, ["--gamma", "--fresnel", "--fsaa", "4"])
 case("test18_160_gf_t4000", "test18", 160, 120, ["--gamma", "--fresnel", "-t", "4000"])
 case("demo03_320x240_aa4_gf", "demo03", 320, 240, ["--fsaa", "4", "--gamma", "--fresnel"])
+# transforms fuzzed inside the engine (oracle/ref_driver.cpp --jitter SEED: every object of the scene's static description
+# gets right-angle or arbitrary rotations, negative / non-unit scalers, a shifted position): scalers before and after
+# rotations, nested transform nodes, mirrored axis maps -- against the reference itself, not only against the oracle
+for scene, seed, extra in (("test05", 1, []), ("test06", 2, []), ("test07", 3, ["--gamma", "--fresnel"]), ("test08", 4, []),
+                           ("test03", 18, []), ("test10", 6, ["--fsaa", "4"]), ("test11", 7, []), ("test12", 8, ["--opts", "none"]),
+                           ("test15", 9, []), ("test17", 18, []), ("test09", 11, ["--opts", "none"]), ("test05", 14, ["--fsaa", "2"]),
+                           ("test18", 18, ["--gamma", "--fresnel"])):
+    case(f"{scene}_160_j{seed}", scene, 160, 120, ["--jitter", str(seed)] + extra)
 # BASELINE.json configs
 case("c1_demo01_640x480", "demo01", 640, 480)
 case("c2_demo01_1080p_d0", "demo01", 1920, 1080, ["--depth", "0"], keep_frame=False)
