@@ -146,11 +146,12 @@ def test_gpu_drop_in_path_tracer_through_reference_engine(args):
     assert hashes[0] == hashes[1], hashes
 
 
-@pytest.mark.parametrize("mode", [[], ["--gather"]])
-def test_gpu_two_rank_bench_path_on_one_gpu(mode):
-    """The N = 2 code path of bench.py -- MultiRender (one multi-target launch per step), the buffer rotation and
-    the grouped exchange / gather -- with the HIP renderer, both ranks on this one GPU (gloo carries the exchange:
-    RCCL refuses two ranks on one device).  The assembled frames must equal the reference-checked frame."""
+@pytest.mark.parametrize("ranks,mode", [(2, []), (2, ["--gather"]), (4, []), (3, ["--gather"])])
+def test_gpu_two_rank_bench_path_on_one_gpu(ranks, mode):
+    """The N > 1 code path of bench.py -- MultiRender (one multi-target launch per step), the buffer rotation and
+    the grouped exchange / gather -- with the HIP renderer, all ranks on this one GPU (gloo carries the exchange:
+    RCCL refuses two ranks on one device).  The assembled frames must equal the reference-checked frame.
+    2, 3 and 4 ranks: 135 tile rows do not divide by 4, and with 3 every rank's blocks sit elsewhere."""
     import json
     import os
     import socket
@@ -159,16 +160,16 @@ def test_gpu_two_rank_bench_path_on_one_gpu(mode):
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, QR_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "7", "--warmup", "2",
            "--workload", "demo2_1080p_gf_d3", "--no-cpu-baseline"] + mode
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["config"]["frame_check"]["ok"] is True
+    assert j["n_gpus"] == ranks and j["config"]["frame_check"]["ok"] is True
     assert j["config"]["frame_check"]["timed_frames_match"] is True and j["config"]["assembled_frame_matches"] is True
-    assert j["collective"]["ranks"] == 2 and j["collective"]["backend"] == "gloo"
+    assert j["collective"]["ranks"] == ranks and j["collective"]["backend"] == "gloo"
 
 
 def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
