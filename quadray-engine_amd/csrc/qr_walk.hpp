@@ -639,7 +639,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #ifdef QR_STATS
             st_skip++;
 #endif
-            pos += 32;
+            pos = __builtin_amdgcn_readfirstlane(pos + 32);
         }
         const u32 op = c.s0;
         if (op == 0) break;
@@ -705,7 +705,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             }
         }
         if (!full) next = c.s2;                 /* every ray that was on is out of the array's reach: nobody enters it */
-        pos = next;
+        pos = __builtin_amdgcn_readfirstlane(next);
     }
     if (SHADOW) occluded = w.resume == 0xFFFFFFFFu;
 #ifdef QR_STATS
