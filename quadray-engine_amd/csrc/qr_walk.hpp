@@ -620,7 +620,9 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
         u32x8 c;
         for (;;)
         {
-            pos = __builtin_amdgcn_readfirstlane(pos);      /* wave-uniform by construction; says so to the compiler */
+            /* `pos` is wave-uniform by construction; every assignment says so to the compiler (readfirstlane of the
+             * new value), which keeps the cursor in an SGPR: with one readfirstlane here instead, it lived in a VGPR
+             * and made the round trip v_mov / v_readfirstlane once per cell */
             QR_GUARD_POS(1, pos, head, return);
             c = *(const QR_CONST u32x8 *)(B + pos);
             if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
