@@ -224,7 +224,7 @@ static void usage()
     fprintf(stderr,
         "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
         "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
-        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim]\n");
+        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim] [--jitter SEED] [--swarm N,SEED]\n");
 }
 
 
@@ -344,13 +344,73 @@ static void jitter_tree(rt_OBJECT *arr, int n, int level)
     }
 }
 
+/*
+ * --swarm N,SEED: N more spheres in the scene, in arrays of up to 12 under one new array of the root -- every group with
+ * a bounding-volume relation, every fourth group rotated (a transform node: its spheres live in its space), some spheres
+ * clipped, materials from plain to glass (none textured: the reference computes no texture coordinates for quadrics --
+ * QD_mat, tracer.cpp:4845-4905, has no texture block -- and reads whatever the context still holds from the last plane).  The engine builds its own lists for them; the fixture pins the kernel and the
+ * list-building pass on a crowd of small quadrics against the reference itself (the synthetic 10 000-object scene of
+ * BASELINE config 5 is of this kind, but the engine's per-surface lists grow with N^2: a few hundred is what fits).
+ */
+static void add_swarm(rt_SCENE *scn, int n, uint64_t seed)
+{
+    static rt_MATERIAL *outer[] = { &mt_plain01_red01, &mt_plain01_blue01, &mt_metal01_cyan01, &mt_metal02_orange01,
+                                    &mt_metal03_nickel01, &mt_glass01_orange01, &mt_air_to_glass03, &mt_plain01_cyan01,
+                                    &mt_plain01_green01, &mt_metal01_pink01 };
+    g_jit = 0xD1B54A32D192ED03ull * (seed + 1);
+    const int per = 12, n_groups = (n + per - 1) / per;
+    rt_SPHERE *sph = (rt_SPHERE *)calloc((size_t)n, sizeof(rt_SPHERE));
+    rt_OBJECT *objs = (rt_OBJECT *)calloc((size_t)n, sizeof(rt_OBJECT));
+    rt_OBJECT *groups = (rt_OBJECT *)calloc((size_t)n_groups, sizeof(rt_OBJECT));
+    rt_RELATION *rels = (rt_RELATION *)calloc((size_t)n_groups, sizeof(rt_RELATION));
+    auto unit = [](rt_TRANSFORM3D &t) { for (int a = 0; a < 3; a++) { t.scl[a] = 1.0f; t.rot[a] = 0.0f; t.pos[a] = 0.0f; } };
+    for (int i = 0; i < n; i++)
+    {
+        rt_SPHERE &sp = sph[i];
+        for (int a = 0; a < 3; a++) { sp.srf.min[a] = -RT_INF; sp.srf.max[a] = +RT_INF; }
+        sp.rad = 0.15f + (rt_real)(jit_next() % 46) / 100.0f;
+        if (jit_next() % 5 == 0 && !getenv("QR_SWARM_NOBOWL")) sp.srf.max[RT_K] = sp.rad * 0.6f;                 /* an open bowl */
+        rt_MATERIAL *m = outer[jit_next() % 10];
+        rt_SIDE side = { { 1.0f, 1.0f }, 0.0f, { 0.0f, 0.0f }, m };
+        sp.srf.side_outer = side;
+        side.pmat = m == &mt_air_to_glass03 ? &mt_glass03_to_air : &mt_plain01_gray01;
+        sp.srf.side_inner = side;
+        rt_OBJECT &o = objs[i];
+        unit(o.trm);
+        o.trm.pos[RT_X] = (rt_real)((int)(jit_next() % 2401) - 1200) / 100.0f;
+        o.trm.pos[RT_Y] = (rt_real)((int)(jit_next() % 2401) - 1200) / 100.0f;
+        o.trm.pos[RT_Z] = 0.4f + (rt_real)(jit_next() % 701) / 100.0f;
+        if (jit_next() % 7 == 0 && !getenv("QR_SWARM_NOSCALE")) o.trm.scl[RT_Z] = 1.5f;                           /* an ellipsoid */
+        o.obj.tag = RT_TAG_SPHERE; o.obj.pobj = &sp; o.obj.obj_num = 1;
+        o.time = -1;
+    }
+    for (int g = 0; g < n_groups; g++)
+    {
+        rt_OBJECT &o = groups[g];
+        unit(o.trm);
+        if (g % 4 == 3 && !getenv("QR_SWARM_NOROT")) { o.trm.rot[RT_Z] = (rt_real)(jit_next() % 360); o.trm.rot[RT_X] = (rt_real)((int)(jit_next() % 41) - 20); }
+        o.obj.tag = RT_TAG_ARRAY; o.obj.pobj = &objs[g * per]; o.obj.obj_num = (g + 1) * per <= n ? per : n - g * per;
+        o.time = -1;
+        rels[g].obj1 = -1; rels[g].rel = RT_REL_BOUND_ARRAY; rels[g].obj2 = g;
+    }
+    const int old_n = scn->root.obj_num;
+    rt_OBJECT *kids = (rt_OBJECT *)calloc((size_t)old_n + 1, sizeof(rt_OBJECT));
+    memcpy(kids, scn->root.pobj, (size_t)old_n * sizeof(rt_OBJECT));
+    rt_OBJECT &sw = kids[old_n];
+    unit(sw.trm);
+    sw.obj.tag = RT_TAG_ARRAY; sw.obj.pobj = groups; sw.obj.obj_num = n_groups; sw.obj.prel = rels; sw.obj.rel_num = n_groups;
+    sw.time = -1;
+    scn->root.pobj = kids; scn->root.obj_num = old_n + 1;
+}
+
 int main(int argc, char **argv)
 {
     int pt_frames = 0;
     const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL, *tree_path = NULL;
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
-    long time_ms = 0, animate_ms = 0;
+    long time_ms = 0, animate_ms = 0, swarm_seed = 0;
+    int swarm_n = 0;
 
     for (int i = 1; i < argc; i++)
     {
@@ -374,6 +434,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
         else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }
+        else if (!strcmp(argv[i], "--swarm") && i + 1 < argc) sscanf(argv[++i], "%d,%ld", &swarm_n, &swarm_seed);
         else if (!strcmp(argv[i], "--jitter") && i + 1 < argc) g_jit = 0x9E3779B97F4A7C15ull * (uint64_t)(atol(argv[++i]) + 1);   /* every frame through ref_shim.cpp -> qr_render0 */
         else { usage(); return 2; }
     }
@@ -381,6 +442,7 @@ int main(int argc, char **argv)
     rt_SCENE *scn = find_scene(scene_name);
     if (scn == NULL) { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
     if (g_threads < 1) g_threads = 1;
+    if (swarm_n > 0 && scn->root.tag == RT_TAG_ARRAY) { add_swarm(scn, swarm_n, (uint64_t)swarm_seed); g_jit = 0; }
     if (g_jit != 0 && scn->root.tag == RT_TAG_ARRAY) jitter_tree((rt_OBJECT *)scn->root.pobj, scn->root.obj_num, 0);
 
     int rc = 0;

@@ -64,6 +64,12 @@ for scene, seed, extra in (("test05", 1, []), ("test06", 2, []), ("test07", 3, [
                            ("test15", 9, []), ("test17", 18, []), ("test09", 11, ["--opts", "none"]), ("test05", 14, ["--fsaa", "2"]),
                            ("test18", 18, ["--gamma", "--fresnel"])):
     case(f"{scene}_160_j{seed}", scene, 160, 120, ["--jitter", str(seed)] + extra)
+# a crowd of small quadrics built INSIDE the engine (oracle/ref_driver.cpp --swarm N,SEED: arrays of 12 spheres with
+# bounding volumes, every fourth group a transform node, bowls, ellipsoids, plain / metal / glass): the scene class of
+# BASELINE config 5 with the engine's own lists, as far as its N^2 per-surface lists allow
+case("swarm_demo01_240", "demo01", 160, 120, ["--swarm", "240,1"])
+case("swarm_demo01_240_gf_aa4", "demo01", 160, 120, ["--swarm", "240,1", "--gamma", "--fresnel", "--fsaa", "4"])
+case("swarm_demo03_200_t3000", "demo03", 160, 120, ["--swarm", "200,2", "-t", "3000"])
 # BASELINE.json configs
 case("c1_demo01_640x480", "demo01", 640, 480)
 case("c2_demo01_1080p_d0", "demo01", 1920, 1080, ["--depth", "0"], keep_frame=False)
