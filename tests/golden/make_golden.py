@@ -70,6 +70,7 @@ for scene, seed, extra in (("test05", 1, []), ("test06", 2, []), ("test07", 3, [
 case("swarm_demo01_240", "demo01", 160, 120, ["--swarm", "240,1"])
 case("swarm_demo01_240_gf_aa4", "demo01", 160, 120, ["--swarm", "240,1", "--gamma", "--fresnel", "--fsaa", "4"])
 case("swarm_demo03_200_t3000", "demo03", 160, 120, ["--swarm", "200,2", "-t", "3000"])
+case("swarm_demo01_240_1080p", "demo01", 1920, 1080, ["--swarm", "240,1"], keep_frame=False)
 # BASELINE.json configs
 case("c1_demo01_640x480", "demo01", 640, 480)
 case("c2_demo01_1080p_d0", "demo01", 1920, 1080, ["--depth", "0"], keep_frame=False)
