@@ -224,7 +224,7 @@ static void usage()
     fprintf(stderr,
         "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
         "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
-        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim] [--jitter SEED] [--swarm N,SEED]\n");
+        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim] [--jitter SEED] [--swarm N,SEED[,MIX]]\n");
 }
 
 
@@ -352,24 +352,42 @@ static void jitter_tree(rt_OBJECT *arr, int n, int level)
  * list-building pass on a crowd of small quadrics against the reference itself (the synthetic 10 000-object scene of
  * BASELINE config 5 is of this kind, but the engine's per-surface lists grow with N^2: a few hundred is what fits).
  */
-static void add_swarm(rt_SCENE *scn, int n, uint64_t seed)
+/* the largest of the quadric records (format.h:496-727): rt_SURFACE + two parameters */
+struct SwarmShape { rt_SURFACE srf; rt_real p0, p1; };
+
+static void add_swarm(rt_SCENE *scn, int n, uint64_t seed, int mix)
 {
     static rt_MATERIAL *outer[] = { &mt_plain01_red01, &mt_plain01_blue01, &mt_metal01_cyan01, &mt_metal02_orange01,
                                     &mt_metal03_nickel01, &mt_glass01_orange01, &mt_air_to_glass03, &mt_plain01_cyan01,
                                     &mt_plain01_green01, &mt_metal01_pink01 };
     g_jit = 0xD1B54A32D192ED03ull * (seed + 1);
     const int per = 12, n_groups = (n + per - 1) / per;
-    rt_SPHERE *sph = (rt_SPHERE *)calloc((size_t)n, sizeof(rt_SPHERE));
+    SwarmShape *sph = (SwarmShape *)calloc((size_t)n, sizeof(SwarmShape));
     rt_OBJECT *objs = (rt_OBJECT *)calloc((size_t)n, sizeof(rt_OBJECT));
     rt_OBJECT *groups = (rt_OBJECT *)calloc((size_t)n_groups, sizeof(rt_OBJECT));
     rt_RELATION *rels = (rt_RELATION *)calloc((size_t)n_groups, sizeof(rt_RELATION));
     auto unit = [](rt_TRANSFORM3D &t) { for (int a = 0; a < 3; a++) { t.scl[a] = 1.0f; t.rot[a] = 0.0f; t.pos[a] = 0.0f; } };
     for (int i = 0; i < n; i++)
     {
-        rt_SPHERE &sp = sph[i];
+        SwarmShape &sp = sph[i];
         for (int a = 0; a < 3; a++) { sp.srf.min[a] = -RT_INF; sp.srf.max[a] = +RT_INF; }
-        sp.rad = 0.15f + (rt_real)(jit_next() % 46) / 100.0f;
-        if (jit_next() % 5 == 0 && !getenv("QR_SWARM_NOBOWL")) sp.srf.max[RT_K] = sp.rad * 0.6f;                 /* an open bowl */
+        const rt_real rad = 0.15f + (rt_real)(jit_next() % 46) / 100.0f;
+        sp.p0 = rad;
+        int tag = RT_TAG_SPHERE;
+        if (jit_next() % 5 == 0 && !getenv("QR_SWARM_NOBOWL")) sp.srf.max[RT_K] = rad * 0.6f;                 /* an open bowl */
+        if (mix)
+        {
+            /* other quadrics, all cut to a finite piece along their axis (MIX): cylinder rad; cone rat; paraboloid par;
+             * hyperboloid rat, hyp (format.h:496-655) */
+            switch (jit_next() % 6)
+            {
+            case 0: tag = RT_TAG_CYLINDER; sp.p0 = rad * 0.6f; sp.srf.min[RT_K] = -rad; sp.srf.max[RT_K] = rad; break;
+            case 1: tag = RT_TAG_CONE; sp.p0 = 0.5f + (rt_real)(jit_next() % 11) / 10.0f; sp.srf.min[RT_K] = -rad; sp.srf.max[RT_K] = (jit_next() & 1) ? 0.0f : rad; break;
+            case 2: tag = RT_TAG_PARABOLOID; sp.p0 = 0.3f + (rt_real)(jit_next() % 8) / 10.0f; sp.srf.min[RT_K] = -RT_INF; sp.srf.max[RT_K] = rad; break;
+            case 3: tag = RT_TAG_HYPERBOLOID; sp.p0 = 0.6f + (rt_real)(jit_next() % 9) / 10.0f; sp.p1 = rad * rad * 0.1f; sp.srf.min[RT_K] = -rad; sp.srf.max[RT_K] = rad; break;
+            default: break;                     /* stays a sphere */
+            }
+        }
         rt_MATERIAL *m = outer[jit_next() % 10];
         rt_SIDE side = { { 1.0f, 1.0f }, 0.0f, { 0.0f, 0.0f }, m };
         sp.srf.side_outer = side;
@@ -381,7 +399,8 @@ static void add_swarm(rt_SCENE *scn, int n, uint64_t seed)
         o.trm.pos[RT_Y] = (rt_real)((int)(jit_next() % 2401) - 1200) / 100.0f;
         o.trm.pos[RT_Z] = 0.4f + (rt_real)(jit_next() % 701) / 100.0f;
         if (jit_next() % 7 == 0 && !getenv("QR_SWARM_NOSCALE")) o.trm.scl[RT_Z] = 1.5f;                           /* an ellipsoid */
-        o.obj.tag = RT_TAG_SPHERE; o.obj.pobj = &sp; o.obj.obj_num = 1;
+        o.obj.tag = tag; o.obj.pobj = &sp; o.obj.obj_num = 1;
+        if (mix && jit_next() % 3 == 0) { o.trm.rot[RT_X] = (rt_real)(90 * (int)(jit_next() % 4)); o.trm.rot[RT_Y] = (rt_real)(90 * (int)(jit_next() % 4)); }   /* axis maps */
         o.time = -1;
     }
     for (int g = 0; g < n_groups; g++)
@@ -410,7 +429,7 @@ int main(int argc, char **argv)
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
     long time_ms = 0, animate_ms = 0, swarm_seed = 0;
-    int swarm_n = 0;
+    int swarm_n = 0, swarm_mix = 0;
 
     for (int i = 1; i < argc; i++)
     {
@@ -434,7 +453,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
         else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }
-        else if (!strcmp(argv[i], "--swarm") && i + 1 < argc) sscanf(argv[++i], "%d,%ld", &swarm_n, &swarm_seed);
+        else if (!strcmp(argv[i], "--swarm") && i + 1 < argc) sscanf(argv[++i], "%d,%ld,%d", &swarm_n, &swarm_seed, &swarm_mix);
         else if (!strcmp(argv[i], "--jitter") && i + 1 < argc) g_jit = 0x9E3779B97F4A7C15ull * (uint64_t)(atol(argv[++i]) + 1);   /* every frame through ref_shim.cpp -> qr_render0 */
         else { usage(); return 2; }
     }
@@ -442,7 +461,7 @@ int main(int argc, char **argv)
     rt_SCENE *scn = find_scene(scene_name);
     if (scn == NULL) { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
     if (g_threads < 1) g_threads = 1;
-    if (swarm_n > 0 && scn->root.tag == RT_TAG_ARRAY) { add_swarm(scn, swarm_n, (uint64_t)swarm_seed); g_jit = 0; }
+    if (swarm_n > 0 && scn->root.tag == RT_TAG_ARRAY) { add_swarm(scn, swarm_n, (uint64_t)swarm_seed, swarm_mix); g_jit = 0; }
     if (g_jit != 0 && scn->root.tag == RT_TAG_ARRAY) jitter_tree((rt_OBJECT *)scn->root.pobj, scn->root.obj_num, 0);
 
     int rc = 0;

@@ -1276,6 +1276,74 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
 #define QR_FLAT_LIST_MAX 128
 #endif
 
+/*
+ * Which sides of surface i a light at `lp` is entered on: 1 inner, 2 outer, 3 both.  This is NOT a cull in the engine
+ * but part of its picture: with RT_OPTS_2SIDED its lsort (engine.cpp:2503-2533) asks bbox_side -> clip_side
+ * (rtgeom.cpp:939-995) where the light stands relative to the surface -- surf_side (894-931: the sign of the quadric
+ * form at the light's position, margin RT_CULL_THRESHOLD), convexity (surf_conc, 718-732), holes (surf_hole, 607-660:
+ * axis clippers that cut, custom clippers) and the clip box (surf_cbox, 802-840) -- and the inside of a closed convex
+ * shell never gets a light that stands outside, whether or not the shell casts a shadow.
+ */
+static int light_sides(const qr_scene_view &v, int i, const float lp[3])
+{
+    const float thr = 0.0001f;                                  /* RT_CULL_THRESHOLD, rtgeom.h:33 */
+    const qr_surface &s = v.srf[i];
+    float p[3] = { lp[0], lp[1], lp[2] };
+    if (s.trnode != QR_NULL)
+    {
+        /* node_tran 775-791: the position in the transform node's space */
+        const qr_surface &t = v.srf[s.trnode];
+        const float d[3] = { lp[0] - t.pos[0], lp[1] - t.pos[1], lp[2] - t.pos[2] };
+        p[0] = t.tci[0] * d[0] + t.tci[1] * d[1] + t.tci[2] * d[2];
+        p[1] = t.tcj[0] * d[0] + t.tcj[1] * d[1] + t.tcj[2] * d[2];
+        p[2] = t.tck[0] * d[0] + t.tck[1] * d[1] + t.tck[2] * d[2];
+    }
+    const bool own = s.trnode == i;
+    float loc[3];
+    for (int a = 0; a < 3; a++) loc[a] = own ? p[a] : p[a] - s.pos[a];
+    const int tag = s.srf_t[3];
+    float d;
+    if (tag == QR_TAG_PLANE)
+    {
+        const int k = (int)((s.axes >> 4) & 3);
+        d = ((s.axes >> 10) & 1) ? -loc[k] : loc[k];
+    }
+    else
+    {
+        /* the snapshot keeps half of the shape's linear coefficients (rt_Quadric::commit_fields, object.cpp:3059-3061) */
+        const float dcj = loc[0] * (s.scj[0] + s.scj[0]) + loc[1] * (s.scj[1] + s.scj[1]) + loc[2] * (s.scj[2] + s.scj[2]);
+        const float dci = loc[0] * loc[0] * s.sci[0] + loc[1] * loc[1] * s.sci[1] + loc[2] * loc[2] * s.sci[2];
+        d = dci - dcj - s.sci[3];
+    }
+    int c = d > thr ? 2 : (d >= -thr ? 0 : 1);
+    if (c == 0) return 3;
+    if (tag == QR_TAG_PLANE) return c;
+    const bool concave = tag == 3 || tag == 5 || tag == 7 || tag == 8;     /* cone, hyperboloid, hypercylinder, hyperparaboloid */
+    if (!concave && c == 1) return c;
+    int hole = (s.minmax_t & 63u) ? 1 : 0;
+    bool skip = false;
+    for (int e = s.clip; e != QR_NULL; e = v.elm[e].next)
+    {
+        const qr_elem &el = v.elm[e];
+        if (el.simd == QR_NULL) { skip = !skip; continue; }     /* accum marker */
+        if (el.kind == 2) continue;                             /* trnode element */
+        (void)skip;
+        hole |= 2;                                              /* any clipper other than the surface itself */
+        break;
+    }
+    if (hole == 0) return c;
+    if (hole & 2) return 3;
+    for (int a = 0; a < 3; a++)
+    {
+        const float off = own ? 0.0f : s.pos[a];
+        const float cmin = (s.minmax_t & (1u << a)) ? s.min[a] + off : -__builtin_inff();
+        const float cmax = (s.minmax_t & (1u << (3 + a))) ? s.max[a] + off : __builtin_inff();
+        /* outside the clip box or on its border (both with the margin): the other side shows through the opening */
+        if (p[a] - thr <= cmin || p[a] + thr >= cmax) return 3;
+    }
+    return c;
+}
+
 int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, std::string &err)
 {
     int rc = qr_snapshot_validate(v, err);
@@ -1312,8 +1380,9 @@ int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, s
             }
         }
         s.lst[1] = side_list[0]; s.lst[3] = side_list[1];
-        /* light list with per-light shadow lists (shared by both sides) */
-        int l_head = QR_NULL, l_tail = QR_NULL;
+        /* light lists of the two sides, per-light shadow lists shared between them; which side a light is entered on is
+         * the engine's rule (light_sides above), not a cull */
+        int l_head[2] = { QR_NULL, QR_NULL }, l_tail[2] = { QR_NULL, QR_NULL };
         for (int l = 0; l < n_lgt; l++)
         {
             int shadow = fr.clist;
@@ -1343,13 +1412,18 @@ int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, s
                     });
                 }
             }
-            qr_elem c; c.simd = l; c.data = shadow; c.next = QR_NULL; c.kind = 0;
-            E.push_back(c);
-            const int ix = (int)E.size() - 1;
-            if (l_tail != QR_NULL) E[l_tail].next = ix; else l_head = ix;
-            l_tail = ix;
+            const int sides = light_sides(v, i, v.lgt[l].pos);
+            for (int side = 0; side < 2; side++)
+            {
+                if (!(sides & (side == 0 ? 2 : 1))) continue;
+                qr_elem c; c.simd = l; c.data = shadow; c.next = QR_NULL; c.kind = 0;
+                E.push_back(c);
+                const int ix = (int)E.size() - 1;
+                if (l_tail[side] != QR_NULL) E[l_tail[side]].next = ix; else l_head[side] = ix;
+                l_tail[side] = ix;
+            }
         }
-        s.lst[0] = l_head; s.lst[2] = l_head;
+        s.lst[0] = l_head[0]; s.lst[2] = l_head[1];
     }
 
     /* serialise the new snapshot: same sections, larger element array */

@@ -229,10 +229,57 @@ def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, bo
     glist = b.link(top_cells)
 
     # light lists.  Default: one light list for everything, every light's shadow list is the global list.
-    llist = b.link([b.cell(l, data=glist) for l in lights])
+    # Which side of a surface a light is entered on is the engine's rule (RT_OPTS_2SIDED: lsort -> bbox_side -> clip_side,
+    # engine.cpp:2503-2533, rtgeom.cpp:939-995; the same rule as light_sides in csrc/qr_compile.cpp): the sign of the
+    # quadric form at the light (margin 1e-4); a convex surface seen from inside shows its inner side only; from outside
+    # the outer side only, unless the surface is concave-capable with holes or the light stands outside its clip box.
+    lpos32 = [b.lgt[l].view(np.float32)[1:4].copy() for l in lights]
+
+    def sides(r, lp):
+        f = r.view(np.float32)
+        tag = int(r[37].view(np.int32)) if hasattr(r[37], "view") else int(np.int32(r[37]))
+        loc = (lp - f[0:3]).astype(np.float32)
+        if tag == 0:
+            k = (int(r[23]) >> 4) & 3
+            d = -loc[k] if (int(r[23]) >> 10) & 1 else loc[k]
+        else:
+            sci, scj = f[24:28], f[28:31]
+            dcj = np.float32(loc[0] * (scj[0] + scj[0]) + loc[1] * (scj[1] + scj[1]) + loc[2] * (scj[2] + scj[2]))
+            dci = np.float32(loc[0] * loc[0] * sci[0] + loc[1] * loc[1] * sci[1] + loc[2] * loc[2] * sci[2])
+            d = np.float32(dci - dcj - sci[3])
+        c = 2 if d > 1e-4 else (0 if d >= -1e-4 else 1)
+        if c == 0:
+            return 3
+        if tag == 0:
+            return c
+        if tag not in (3, 5, 7, 8) and c == 1:
+            return c
+        mm = int(r[7]) & 63
+        if mm == 0:
+            return c
+        for a in range(3):
+            cmin = f[4 + a] + f[a] if mm & (1 << a) else -np.inf
+            cmax = f[8 + a] + f[a] if mm & (1 << (3 + a)) else np.inf
+            if lp[a] - 1e-4 <= cmin or lp[a] + 1e-4 >= cmax:
+                return 3
+        return c
+
+    def light_lists(r, cells):
+        """cells: one (light, shadow list) per light -> heads of the outer and the inner light list of surface r"""
+        out = []
+        for want in (2, 1):
+            key = tuple((l, sh) for (l, sh), lp in zip(cells, lpos32) if sides(r, lp) & want)
+            if key not in shared:                     # equal lists are one list (every light on the global shadow list: shared by all)
+                shared[key] = b.link([b.cell(l, data=sh) for l, sh in key]) if key else NULL
+            out.append(shared[key])
+        return out
+
+    shared = {}
+
     for r in b.srf:
         if int(r[37]) < TAG_BOUND:
-            r[44:48] = np.array([llist, glist, llist, glist], dtype=np.int32).view(np.uint32)
+            lo, li_ = light_lists(r, [(l, glist) for l in lights])
+            r[44:48] = np.array([lo, glist, li_, glist], dtype=np.int32).view(np.uint32)
     if shadow_lists and obj:
         # Per object and light, the engine's kind of shadow list (ssort/lsort + bbox_shad, engine.cpp:2134-2753):
         # only the objects that can stand between the light and this object -- those whose bounding sphere
@@ -258,8 +305,8 @@ def make_scene(n_objects=10000, width=7680, height=4320, depth=4, seed=12345, bo
                 for j in range(len(d)):
                     heads[c0 + j, li] = b.link([b.cell(obj[y][0]) for y in np.nonzero(hit[j])[0]])
         for k, (s, c, r) in enumerate(obj):
-            ll = b.link([b.cell(l, data=int(heads[k, li])) for li, l in enumerate(lights)])
-            b.srf[s][44] = np.uint32(ll & 0xFFFFFFFF); b.srf[s][46] = np.uint32(ll & 0xFFFFFFFF)
+            lo, li_ = light_lists(b.srf[s], [(l, int(heads[k, li])) for li, l in enumerate(lights)])
+            b.srf[s][44] = np.uint32(lo & 0xFFFFFFFF); b.srf[s][46] = np.uint32(li_ & 0xFFFFFFFF)
 
     # ---- camera: outside a corner of the box, looking at its centre ------------------------------
     eye = np.array([-0.95 * box, -1.25 * box, 0.9 * box + 1.5])

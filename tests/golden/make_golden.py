@@ -71,6 +71,10 @@ case("swarm_demo01_240", "demo01", 160, 120, ["--swarm", "240,1"])
 case("swarm_demo01_240_gf_aa4", "demo01", 160, 120, ["--swarm", "240,1", "--gamma", "--fresnel", "--fsaa", "4"])
 case("swarm_demo03_200_t3000", "demo03", 160, 120, ["--swarm", "200,2", "-t", "3000"])
 case("swarm_demo01_240_1080p", "demo01", 1920, 1080, ["--swarm", "240,1"], keep_frame=False)
+# the same with every kind of quadric (--swarm N,SEED,1: cut cylinders, cones, paraboloids, hyperboloids, axis maps from
+# right-angle turns); 24 more such scenes (3 stock scenes x 8 seeds) agreed with the oracle when these were made
+case("swarm_demo01_240_mix", "demo01", 160, 120, ["--swarm", "240,3,1"])
+case("swarm_demo02_200_mix_gf", "demo02", 160, 120, ["--swarm", "200,4,1", "--gamma", "--fresnel"])
 # BASELINE.json configs
 case("c1_demo01_640x480", "demo01", 640, 480)
 case("c2_demo01_1080p_d0", "demo01", 1920, 1080, ["--depth", "0"], keep_frame=False)

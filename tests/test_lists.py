@@ -22,12 +22,14 @@ def _synth():
 
 
 def _two_sided_slack(name):
-    """Pixels that may differ from the reference with rebuilt lists.  The engine's light lists are not only a cull: with
-    RT_OPTS_2SIDED (engine.cpp:2503-2533) a light goes to the outer OR the inner side of a quadric by where it stands
-    (bbox_side), so the inside of a shell is never lit from outside -- also when the shell casts no shadow (transparent,
-    not refractive) or is open (clipped).  The pass gives every light to both sides and lets the shadow rays decide, which
-    lights such an inside: the stock scenes have no such surface (0 pixels), the swarm scenes one or two pixels."""
-    return 2 if name.startswith("swarm_") else 0
+    """Pixels that may differ from the reference with rebuilt lists.  Light lists follow the engine's rule for the side a
+    light is entered on (light_sides in qr_compile.cpp = clip_side, rtgeom.cpp:939-995: equal to the engine's lists on
+    every surface side of the swarm fixtures).  What is left: the engine's per-side SURFACE lists of a quadric hold only
+    what its box predicates (bbox_side, rtgeom.cpp:1954-2128) place on that side of the CLIPPED shape, so a ray that
+    travels inside an open bowl and leaves through the opening passes surfaces standing in the cut-away part of the ball
+    unseen; the pass keeps the whole list for quadrics and finds them.  The stock scenes have no such geometry (0 pixels),
+    the swarm fixtures up to six pixels of 19 200 (hit ids equal)."""
+    return 6 if name.startswith("swarm_") else 0
 
 
 @pytest.mark.parametrize("name", CPU_CASES)
@@ -111,5 +113,6 @@ def test_gpu_rebuilt_lists_keep_pixels_and_hit_ids(qr, name):
     assert int((f1.cpu().numpy().view(np.uint32) != (load_frame(name) & 0xFFFFFF)).sum()) <= _two_sided_slack(name)
     assert bool((i0 == i1).all())
     _, c0 = base.render_count(); _, c1 = scn.render_count()
-    # the engine also drops lights a side cannot see: our light lists keep every light, so shadow rays can only be more
-    assert c1.primary == c0.primary and c1.reflect == c0.reflect and c1.refract == c0.refract and c1.shadow >= c0.shadow
+    # shadow rays may be more (wider shadow lists never change a light's visibility test count, but a `--opts none`
+    # snapshot enters every light on both sides where the pass follows the 2-sided rule) or fewer: not compared
+    assert c1.primary == c0.primary and c1.reflect == c0.reflect and c1.refract == c0.refract
