@@ -25,10 +25,10 @@ def _two_sided_slack(name):
     """Pixels that may differ from the reference with rebuilt lists.  Light lists follow the engine's rule for the side a
     light is entered on (light_sides in qr_compile.cpp = clip_side, rtgeom.cpp:939-995: equal to the engine's lists on
     every surface side of the swarm fixtures).  What is left: the engine's per-side SURFACE lists of a quadric hold only
-    what its box predicates (bbox_side, rtgeom.cpp:1954-2128) place on that side of the CLIPPED shape, so a ray that
-    travels inside an open bowl and leaves through the opening passes surfaces standing in the cut-away part of the ball
-    unseen; the pass keeps the whole list for quadrics and finds them.  The stock scenes have no such geometry (0 pixels),
-    the swarm fixtures up to six pixels of 19 200 (hit ids equal)."""
+    what its box predicates (bbox_side, rtgeom.cpp:1954-2128) place on that side of the clipped shape; the pass keeps the
+    whole list for quadrics, and in a crowd of interpenetrating open shells that is not the same picture (putting the
+    engine's inner-side list of one transparent bowl back restores the reference's pixel).  The stock scenes: 0 pixels;
+    the swarm fixtures: up to six of 19 200, hit ids equal."""
     return 6 if name.startswith("swarm_") else 0
 
 
