@@ -461,7 +461,7 @@ int main(int argc, char **argv)
     rt_SCENE *scn = find_scene(scene_name);
     if (scn == NULL) { fprintf(stderr, "unknown scene %s\n", scene_name); return 2; }
     if (g_threads < 1) g_threads = 1;
-    if (swarm_n > 0 && scn->root.tag == RT_TAG_ARRAY) { add_swarm(scn, swarm_n, (uint64_t)swarm_seed, swarm_mix); g_jit = 0; }
+    if (swarm_n > 0 && scn->root.tag == RT_TAG_ARRAY) { const uint64_t keep = g_jit; add_swarm(scn, swarm_n, (uint64_t)swarm_seed, swarm_mix); g_jit = keep; }
     if (g_jit != 0 && scn->root.tag == RT_TAG_ARRAY) jitter_tree((rt_OBJECT *)scn->root.pobj, scn->root.obj_num, 0);
 
     int rc = 0;

@@ -31,7 +31,9 @@ EXTRA = {
 # shifted positions on every object of the scene's static description): tree + the snapshot of that run with its texels
 # zeroed (the hierarchy tests do not look at them; 160 KB of texture would travel with every case otherwise)
 FUZZ = [("test14", 1, []), ("test14", 2, []), ("test14", 3, ["--opts", "none"]), ("test14", 4, []),
-        ("test13", 1, []), ("test16", 1, []), ("demo02", 1, []), ("test12", 1, ["--opts", "none"]), ("test09", 5, [])]
+        ("test13", 1, []), ("test16", 1, []), ("demo02", 1, []), ("test12", 1, ["--opts", "none"]), ("test09", 5, []),
+        # seed 0: no jitter, the extra arguments make the scene (a swarm of mixed quadrics under rotated groups, then jittered too)
+        ("demo03", 0, ["--swarm", "96,5,1"]), ("test09", 7, ["--swarm", "60,6,1"])]
 
 
 def run(scene, w, h, args, tmp):
@@ -73,11 +75,11 @@ def fuzz():
     import struct
     for scene, seed, args in FUZZ:
         tmp = tempfile.mkdtemp(prefix="qrtree_")
-        _, blob, tree = run(scene, 32, 24, ["--jitter", str(seed)] + args, tmp)
+        _, blob, tree = run(scene, 32, 24, (["--jitter", str(seed)] if seed else []) + args, tmp)
         b = bytearray(blob)
         n_texels, off_texels = struct.unpack_from("<I", b, 4 * 9)[0], struct.unpack_from("<I", b, 4 * 16)[0]
         b[off_texels:off_texels + 4 * n_texels] = bytes(4 * n_texels)
-        name = "fuzz_%s_s%d%s" % (scene, seed, "_noopt" if args else "")
+        name = "fuzz_%s_s%d%s" % (scene, seed, "_swarm" if "--swarm" in args else ("_noopt" if args else ""))
         with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
             f.write(gzip.compress(tree, 9, mtime=0))
         with open(os.path.join(OUT, name + ".qrs.gz"), "wb") as f:
