@@ -920,6 +920,9 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     lp.stats = c.d_counters + 4;
     const uint32_t *d_order = (const uint32_t *)((const char *)c.d_blob + c.prog.off_order);
     const int K = (int)c.prog.block_first.size() - 1;
+    /* kernel instance as for uploaded scenes: QR_DIV=0 / 1 forces it (experiments, tests); shadow grids need the per-lane one */
+    static const int force_div = []() { const char *dv = getenv("QR_DIV"); return dv ? (atoi(dv) != 0 ? 1 : 0) : -1; }();
+    const bool divk = (force_div >= 0 ? force_div != 0 : c.prog.has_long_lists) || c.prog.has_grids;
     hipError_t e = hipSuccess;
     for (int k = 0; k < K && e == hipSuccess; k++)
     {
@@ -932,7 +935,7 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
             if (fr.pt_on)
                 hipLaunchKernelGGL(qr_render_pt_kernel, dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
                                    lp, pt, (uint32_t *)c.d_frame, c.d_counters);
-            else if (c.prog.has_long_lists || c.prog.has_grids)
+            else if (divk)
                 hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
             else
