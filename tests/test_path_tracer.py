@@ -191,7 +191,8 @@ def test_gpu_eager_path_tracer_with_fsaa_gamma_fresnel(qr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["test18_160", "demo01_160", "demo02_160", "demo03_160", "test09_160", "test13_160", "test16_160"])
+@pytest.mark.parametrize("name", ["test18_160", "demo01_160", "demo02_160", "demo03_160", "test09_160", "test13_160", "test16_160",
+                                  "swarm_demo01_240_mix", "test11_160_j7"])
 def test_gpu_eager_machine_with_ray_tracer_shading_is_the_ray_tracer(qr, name):
     """Self-test of the eager machine: with the ray tracer's shading (lights, shadows, no random numbers) shading every
     provisional hit cannot change a pixel, so its frame is the deferred kernel's, at every depth -- also on the scenes
