@@ -49,6 +49,10 @@ WORKLOADS = {
     "demo2_2160p_aa4": ("c4_demo02_2160p_aa4_gf",
                         ["--scene", "demo02", "-w", "3840", "-h", "2160", "--gamma", "--fresnel", "--fsaa", "4"],
                         "demo scene 2 @3840x2160, 4x FSAA, Gamma+Fresnel"),
+    # a crowd built inside the engine (oracle/ref_driver.cpp --swarm): demo scene 1 + 240 quadrics in bounding-volume
+    # arrays, the engine's own lists; the densest scene that is gated by a reference frame and timed against the reference
+    "swarm_1080p": ("swarm_demo01_240_1080p", ["--scene", "demo01", "-w", "1920", "-h", "1080", "--swarm", "240,1"],
+                    "demo scene 1 + a swarm of 240 spheres / bowls / ellipsoids (plain, metal, glass) @1920x1080, depth 10"),
     # BASELINE.json config 5: not a reference scene (quadray-engine_amd/synth.py builds the snapshot, the GPU
     # binning pass its tile lists); the CPU baseline is the oracle port on a sample of rows
     "synth10k_4320p": ("synth:10000:7680:4320:4", None,

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import qr_oracle
 
-SNAPS = ["c2b_demo01_1080p", "c2_demo01_1080p_d0", "c3_demo02_1080p_gf_d3", "c4_demo02_2160p_aa4_gf"]
+SNAPS = ["c2b_demo01_1080p", "c2_demo01_1080p_d0", "c3_demo02_1080p_gf_d3", "c4_demo02_2160p_aa4_gf", "swarm_demo01_240_1080p"]
 out = {}
 for name in SNAPS:
     blob = gzip.decompress(open(os.path.join(HERE, name + ".qrs.gz"), "rb").read())
