@@ -714,6 +714,8 @@ struct DropIn
     uint32_t *h_frame = nullptr; size_t hf_cap = 0;
     unsigned long long *d_counters = nullptr;
     hipStream_t sk = nullptr, sc = nullptr;
+    hipStream_t sx[QR_DROPIN_BLOCKS] = {};     /* one launch stream per row block (sx[0] == sk): a block's tail overlaps the next block's bulk */
+    hipEvent_t ev_up = nullptr;                 /* uploads of this call are on the device */
     hipEvent_t ev_k[QR_DROPIN_BLOCKS] = {}, ev_c[QR_DROPIN_BLOCKS] = {};
     std::vector<uint8_t> blob, last_blob;
     QrProgram prog;
@@ -737,6 +739,9 @@ static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_b
         c.device = dev;
         HIP_TRY(hipStreamCreateWithFlags(&c.sk, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c.sc, hipStreamNonBlocking));
+        c.sx[0] = c.sk;
+        for (int k = 1; k < QR_DROPIN_BLOCKS; k++) HIP_TRY(hipStreamCreateWithFlags(&c.sx[k], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
         for (int k = 0; k < QR_DROPIN_BLOCKS; k++)
         {
             HIP_TRY(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
@@ -924,8 +929,14 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     static const int force_div = []() { const char *dv = getenv("QR_DIV"); return dv ? (atoi(dv) != 0 ? 1 : 0) : -1; }();
     const bool divk = (force_div >= 0 ? force_div != 0 : c.prog.has_long_lists) || c.prog.has_grids;
     hipError_t e = hipSuccess;
+    /* QR_DROPIN_STREAMS=1: every block on one stream (A/B) */
+    static const bool one_stream = []() { const char *v = getenv("QR_DROPIN_STREAMS"); return v && atoi(v) == 1; }();
+    e = hipEventRecord(c.ev_up, c.sk);
     for (int k = 0; k < K && e == hipSuccess; k++)
     {
+        hipStream_t sk = one_stream ? c.sk : c.sx[k % QR_DROPIN_BLOCKS];
+        if (sk != c.sk) e = hipStreamWaitEvent(sk, c.ev_up, 0);
+        if (e != hipSuccess) break;
         const uint32_t e0 = c.prog.block_first[k], e1 = c.prog.block_first[k + 1];
         lp.order = d_order + 2 * (size_t)e0;
         lp.n_blocks = (int32_t)(e1 - e0);
@@ -933,23 +944,25 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         if (lp.n_blocks > 0)
         {
             if (fr.pt_on)
-                hipLaunchKernelGGL(qr_render_pt_kernel, dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                hipLaunchKernelGGL(qr_render_pt_kernel, dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
                                    lp, pt, (uint32_t *)c.d_frame, c.d_counters);
             else if (divk)
-                hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
             else
-                hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, c.sk,
+                hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
                                    lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
         }
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(c.ev_k[k], c.sk);
+        if (e == hipSuccess) e = hipEventRecord(c.ev_k[k], sk);
         /* copy block k back as soon as it is rendered, on the copy stream */
         if (e == hipSuccess) e = hipStreamWaitEvent(c.sc, c.ev_k[k], 0);
         const size_t off = (size_t)lp.row_begin * w, n = (size_t)(lp.row_end - lp.row_begin) * w * 4;
         if (e == hipSuccess && n > 0) e = hipMemcpyAsync(c.h_frame + off, (const uint32_t *)c.d_frame + off, n, hipMemcpyDeviceToHost, c.sc);
         if (e == hipSuccess) e = hipEventRecord(c.ev_c[k], c.sc);
     }
+    if (fr.pt_on)
+        for (int k = 0; k < K && e == hipSuccess; k++) e = hipStreamWaitEvent(c.sk, c.ev_k[k], 0);   /* the planes go back when every block is done */
     if (fr.pt_on && e == hipSuccess) e = dropin_pt_end(c, ptio);    /* the planes with this frame's sample go back to the engine */
     const double t4 = now_ms();
     /* the host moves finished blocks into the caller's frame: only the rows this call owns (index / thnum),
