@@ -703,6 +703,9 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
  */
 #ifndef QR_DROPIN_BLOCKS
 #define QR_DROPIN_BLOCKS 4
+#ifndef QR_DROPIN_STREAMS
+#define QR_DROPIN_STREAMS 3     /* measured through the engine, demo1 / demo1 + swarm, ms per frame: 1: 0.83 / 14.1, 2: 0.75 / 12.3, 3: 0.76 / 11.3, 4: 0.83 / 12.1 */
+#endif
 #endif
 
 struct DropIn
@@ -929,12 +932,13 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     static const int force_div = []() { const char *dv = getenv("QR_DIV"); return dv ? (atoi(dv) != 0 ? 1 : 0) : -1; }();
     const bool divk = (force_div >= 0 ? force_div != 0 : c.prog.has_long_lists) || c.prog.has_grids;
     hipError_t e = hipSuccess;
-    /* QR_DROPIN_STREAMS=1: every block on one stream (A/B) */
-    static const bool one_stream = []() { const char *v = getenv("QR_DROPIN_STREAMS"); return v && atoi(v) == 1; }();
+    /* QR_DROPIN_STREAMS=n: blocks on n streams in turn (1: one after the other) */
+    static const int n_streams = []() { const char *v = getenv("QR_DROPIN_STREAMS"); const int n = v ? atoi(v) : QR_DROPIN_STREAMS;
+                                        return n < 1 ? 1 : (n > QR_DROPIN_BLOCKS ? QR_DROPIN_BLOCKS : n); }();
     e = hipEventRecord(c.ev_up, c.sk);
     for (int k = 0; k < K && e == hipSuccess; k++)
     {
-        hipStream_t sk = one_stream ? c.sk : c.sx[k % QR_DROPIN_BLOCKS];
+        hipStream_t sk = c.sx[k % n_streams];
         if (sk != c.sk) e = hipStreamWaitEvent(sk, c.ev_up, 0);
         if (e != hipSuccess) break;
         const uint32_t e0 = c.prog.block_first[k], e1 = c.prog.block_first[k + 1];
