@@ -178,7 +178,10 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
                  * their sphere) */
                 BBox bx;
                 (void)bound_sphere(v, el.simd, &bx);
-                if (bx.valid && vx && vy)
+                static const int box_mode = []() { const char *e = getenv("QR_BIN_BOX"); return e ? atoi(e) : 2; }();
+                /* box_mode (QR_BIN_BOX, diagnosis): 0 spheres only; 1 boxes of surfaces without scaling or transform node; 2 all (default) */
+                const bool box_ok = box_mode == 2 || (box_mode == 1 && q.has_trm == 0 && q.shift == 0);
+                if (bx.valid && vx && vy && box_ok)
                 {
                     /* camera-space corners; the part of the box in front of the plane z = zn is the convex hull
                      * of the corners in front and of the points where box edges cross that plane, so the

@@ -895,7 +895,18 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         qr_bound_spheres(v, bsph);
         E.assign(v.elm, v.elm + v.hdr->n_elm);
         T.assign(v.tiles, v.tiles + v.hdr->n_tiles);
-        rc = qr_program_build(v, E, T, *v.frame, bsph, c.prog, err, QR_DROPIN_BLOCKS);
+        qr_frame frm = *v.frame;
+        /* QR_REBIN=1: the per-tile lists are rebuilt on the GPU from the camera list instead of taken from the engine
+         * (same frames; the engine may then run without its own tiling, RT_OPTS_TILING) */
+        static const bool rebin = []() { const char *v = getenv("QR_REBIN"); return v && atoi(v) != 0; }();
+        if (rebin)
+        {
+            rc = pick_device(dev);
+            if (rc != QR_OK) return rc;
+            rc = rebin_tiles(v, bsph, frm, E, T);
+            if (rc != QR_OK) return rc;
+        }
+        rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, QR_DROPIN_BLOCKS);
         if (rc != QR_OK) return qr_fail(rc, err);
     }
     const double t2 = now_ms();
