@@ -165,7 +165,9 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
         {
             const BSphere &bs = bsph[el.simd];
             b.x0 = 0; b.y0 = 0; b.x1 = frm.tls_row - 1; b.y1 = frm.tls_col - 1;
-            if (cam_ok && bs.r < 1e30f)
+            static const int diag = []() { const char *e = getenv("QR_BIN_DIAG"); return e ? atoi(e) : 0; }();   /* diagnosis: 1 transformed surfaces cover the screen, 2 all do */
+            const bool full = diag == 2 || (diag == 1 && (q.has_trm != 0 || q.shift != 0));
+            if (cam_ok && bs.r < 1e30f && !full)
             {
                 const double R = (double)bs.r * 1.001 + 1e-6;
                 double a = 0.0, bb = 0.0, z = 0.0;
