@@ -47,43 +47,48 @@ float cos_deg(float a)
     return cosf((float)((double)a * 3.14159265358979323846 / 180.0));
 }
 
-/* position * rot_z * rot_y * rot_x * scale, built right to left (matrix_from_transform, rtgeom.cpp:102-162) */
+/* The object's matrix: scale first, then the turns about x, y and z, then the shift -- each step multiplied on from the
+ * left with the full 4x4 product, so every element sees the roundings (and the signed zeros) the engine's chain of
+ * matrix_mul_matrix calls produces (matrix_from_transform, rtgeom.cpp:102-162).  A turn about axis `ax` by angle w is
+ * the identity with [p][p] = [q][q] = cos w, [p][q] = sin w, [q][p] = -sin w for p = ax + 1, q = ax + 2 (mod 3). */
 void from_transform(M4 out, const qr_node &nd, bool with_scale)
 {
-    M4 sc, rx, ry, rz, ps, t0, t1;
-    memcpy(sc, kIden, sizeof(M4)); memcpy(rx, kIden, sizeof(M4)); memcpy(ry, kIden, sizeof(M4));
-    memcpy(rz, kIden, sizeof(M4)); memcpy(ps, kIden, sizeof(M4));
-    if (with_scale) { sc[0][0] = nd.scl[0]; sc[1][1] = nd.scl[1]; sc[2][2] = nd.scl[2]; }
-    const float sx = sin_deg(nd.rot[0]), cx = cos_deg(nd.rot[0]);
-    const float sy = sin_deg(nd.rot[1]), cy = cos_deg(nd.rot[1]);
-    const float sz = sin_deg(nd.rot[2]), cz = cos_deg(nd.rot[2]);
-    rx[1][1] = cx; rx[1][2] = sx; rx[2][1] = -sx; rx[2][2] = cx;
-    ry[0][0] = cy; ry[0][2] = -sy; ry[2][0] = sy; ry[2][2] = cy;
-    rz[0][0] = cz; rz[0][1] = sz; rz[1][0] = -sz; rz[1][1] = cz;
-    ps[3][0] = nd.pos[0]; ps[3][1] = nd.pos[1]; ps[3][2] = nd.pos[2];
-    mul(t0, rx, sc);
-    mul(t1, ry, t0);
-    mul(t0, rz, t1);
-    mul(out, ps, t0);
+    M4 acc, step, nxt;
+    memcpy(acc, kIden, sizeof(M4));
+    for (int ax = 0; ax < 3; ax++) if (with_scale) acc[ax][ax] = nd.scl[ax];
+    for (int ax = 0; ax < 3; ax++)
+    {
+        const int p = (ax + 1) % 3, q = (ax + 2) % 3;
+        const float sn = sin_deg(nd.rot[ax]), cs = cos_deg(nd.rot[ax]);
+        memcpy(step, kIden, sizeof(M4));
+        step[p][p] = cs; step[p][q] = sn; step[q][p] = -sn; step[q][q] = cs;
+        mul(nxt, step, acc);
+        memcpy(acc, nxt, sizeof(M4));
+    }
+    memcpy(step, kIden, sizeof(M4));
+    for (int ax = 0; ax < 3; ax++) step[3][ax] = nd.pos[ax];
+    mul(out, step, acc);
 }
 
-/* inverse of the upper-left 3x3 by cofactors (matrix_inverse, rtgeom.cpp:167-193) */
+/* Inverse of the upper-left 3x3 as adjugate / determinant (matrix_inverse, rtgeom.cpp:167-193).  With indices taken
+ * mod 3, element [r][c] of the adjugate is m[c+1][r+1] m[c+2][r+2] - m[c+2][r+1] m[c+1][r+2]; the determinant expands
+ * along column 0 with the adjugate's first row, summed left to right; every element is then scaled by 1 / det (one
+ * rounding each: the engine multiplies by the reciprocal, it does not divide). */
 void inverse3(M4 out, const M4 m)
 {
     memset(out, 0, sizeof(M4));
-    const float a = m[1][1] * m[2][2] - m[2][1] * m[1][2];
-    const float b = m[2][1] * m[0][2] - m[0][1] * m[2][2];
-    const float c = m[0][1] * m[1][2] - m[1][1] * m[0][2];
-    const float d = m[2][0] * m[1][2] - m[1][0] * m[2][2];
-    const float e = m[0][0] * m[2][2] - m[2][0] * m[0][2];
-    const float f = m[0][2] * m[1][0] - m[0][0] * m[1][2];
-    const float g = m[1][0] * m[2][1] - m[2][0] * m[1][1];
-    const float h = m[2][0] * m[0][1] - m[0][0] * m[2][1];
-    const float l = m[0][0] * m[1][1] - m[1][0] * m[0][1];
-    const float q = 1.0f / (m[0][0] * a + m[1][0] * b + m[2][0] * c);
-    out[0][0] = a * q; out[0][1] = b * q; out[0][2] = c * q;
-    out[1][0] = d * q; out[1][1] = e * q; out[1][2] = f * q;
-    out[2][0] = g * q; out[2][1] = h * q; out[2][2] = l * q;
+    float adj[3][3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+        {
+            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+            adj[r][c] = m[c1][r1] * m[c2][r2] - m[c2][r1] * m[c1][r2];
+        }
+    float det = m[0][0] * adj[0][0];
+    for (int k = 1; k < 3; k++) det = det + m[k][0] * adj[0][k];
+    const float rdet = 1.0f / det;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) out[r][c] = adj[r][c] * rdet;
 }
 
 /* what a node hands to its children (rt_Array::update_object, object.cpp:1739-1756) */
