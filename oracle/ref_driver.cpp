@@ -224,7 +224,7 @@ static void usage()
     fprintf(stderr,
         "usage: qr_ref --scene NAME [-w W] [-h H] [-t MS] [--fsaa 0|2|4] [--gamma] [--fresnel]\n"
         "              [--depth D] [--simd N,K,S] [--opts none|full] [--threads T]\n"
-        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--shim] [--jitter SEED] [--swarm N,SEED[,MIX]]\n");
+        "              [--out F.raw] [--snapshot F.qrs] [--tree F.json] [--bench N] [--camera K] [--pt N] [--pt-warm] [--opts-off tiling,varray,..] [--shim] [--jitter SEED] [--swarm N,SEED[,MIX]]\n");
 }
 
 
@@ -425,7 +425,8 @@ static void add_swarm(rt_SCENE *scn, int n, uint64_t seed, int mix)
 int main(int argc, char **argv)
 {
     int pt_frames = 0;
-    const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL, *tree_path = NULL;
+    const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL, *tree_path = NULL, *opts_off = NULL;
+    int pt_warm = 0;
     int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
     long time_ms = 0, animate_ms = 0, swarm_seed = 0;
@@ -443,6 +444,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--depth") && i + 1 < argc) depth = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--simd") && i + 1 < argc) sscanf(argv[++i], "%d,%d,%d", &n_simd, &k_size, &s_type);
         else if (!strcmp(argv[i], "--opts") && i + 1 < argc) opts_mode = argv[++i];
+        else if (!strcmp(argv[i], "--opts-off") && i + 1 < argc) opts_off = argv[++i];
+        else if (!strcmp(argv[i], "--pt-warm")) pt_warm = 1;
         else if (!strcmp(argv[i], "--threads") && i + 1 < argc) g_threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
         else if (!strcmp(argv[i], "--snapshot") && i + 1 < argc) snap_path = argv[++i];
@@ -486,6 +489,20 @@ int main(int argc, char **argv)
         {
             sc->set_opts(!strcmp(opts_mode, "none") ? RT_OPTS_NONE : RT_OPTS_FULL);
         }
+        if (opts_off != NULL)
+        {
+            /* --opts-off NAME[,NAME]: every optimisation on except the named ones (format.h:40-106); "tiling" is the
+             * screen tiling of engine.cpp:1956-2128, 3129-3253 together with its margin extension */
+            rt_si32 off = 0;
+            if (strstr(opts_off, "tiling")) off |= RT_OPTS_TILING | RT_OPTS_TILING_EXT1;
+            if (strstr(opts_off, "varray")) off |= RT_OPTS_VARRAY;
+            if (strstr(opts_off, "tarray")) off |= RT_OPTS_TARRAY;
+            if (strstr(opts_off, "2sided")) off |= RT_OPTS_2SIDED | RT_OPTS_2SIDED_EXT1 | RT_OPTS_2SIDED_EXT2;
+            if (strstr(opts_off, "shadow")) off |= RT_OPTS_SHADOW | RT_OPTS_SHADOW_EXT1 | RT_OPTS_SHADOW_EXT2;
+            if (strstr(opts_off, "render")) off |= RT_OPTS_RENDER;
+            if (off == 0) { fprintf(stderr, "--opts-off: no known optimisation in '%s'\n", opts_off); return 2; }
+            sc->set_opts(RT_OPTS_FULL & ~off);
+        }
         if (depth >= 0)
         {
             if (depth > RT_STACK_DEPTH) depth = RT_STACK_DEPTH;
@@ -497,7 +514,7 @@ int main(int argc, char **argv)
          * planes, the frame shows their running mean */
         if (pt_frames > 0)
         {
-            if (getenv("QR_REF_PT_WARM"))
+            if (pt_warm || getenv("QR_REF_PT_WARM"))
             {
                 /* experiment: one path-traced frame, then restart the accumulation (seeds and planes are reset) */
                 sc->set_pton(1); sc->render(time_ms); sc->set_pton(0); sc->render(time_ms);   /* the ray-traced frame resets the sample count, tracer.cpp:1128-1132 */

@@ -257,10 +257,15 @@ extern "C" int qr_scene_set_pt(qr_device_scene *s, int on)
     if (!on) { s->pt_on = false; return QR_OK; }
     const size_t n = (size_t)s->fr.frm_row * s->fr.frm_h * ((size_t)1 << s->fr.fsaa);
     if (s->fr.frm_row < s->fr.frm_w || n == 0 || n > ((size_t)1 << 30)) return qr_fail(QR_ERR_ARG, "bad frame stride for the sample planes");
-    if (s->d_seeds == nullptr)
+    if (s->d_seeds == nullptr || s->d_acc == nullptr)
     {
-        HIP_TRY(hipMalloc((void **)&s->d_seeds, n * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&s->d_acc, 3 * n * sizeof(float)));
+        /* both planes or neither: a half-built pair would be taken for a finished one by the next call */
+        uint32_t *seeds_dev = nullptr; float *acc_dev = nullptr;
+        HIP_TRY(hipMalloc((void **)&seeds_dev, n * sizeof(uint32_t)));
+        const hipError_t ea = hipMalloc((void **)&acc_dev, 3 * n * sizeof(float));
+        if (ea != hipSuccess) { (void)hipFree(seeds_dev); return qr_fail(QR_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(ea)); }
+        (void)hipFree(s->d_seeds); (void)hipFree(s->d_acc);
+        s->d_seeds = seeds_dev; s->d_acc = acc_dev;
     }
     std::vector<uint32_t> seeds(n);
     unsigned long long seed = 1;
@@ -382,9 +387,22 @@ static hipError_t launch(qr_device_scene *s, void *frame_dev, int32_t *ids_dev, 
     return hipGetLastError();
 }
 
+/* A path-traced frame is ONE more sample of every pixel sample: the sample count (and with it the weights of the running
+ * mean, tracer.cpp:1112-1136) advances once per launch, so a frame cut into several row-range launches would weigh its
+ * later ranges wrongly.  Such launches are refused; the drop-in entry point, where the engine itself cuts a frame into
+ * index / thnum slices, takes the count from the caller's s_inf instead (dropin_pt_begin). */
+static int pt_rows_ok(const qr_device_scene *s)
+{
+    if (!s->pt_on) return QR_OK;
+    const bool whole = s->lp.row_begin == 0 && s->lp.row_end == s->fr.frm_h && s->lp.group_first == 0 && s->lp.group_stride == 1 && s->lp.thnum <= 1;
+    if (!whole) return qr_fail(QR_ERR_UNSUP, "path-tracer mode renders whole frames only: reset qr_scene_set_rows / qr_scene_set_tile_rows to the full frame");
+    return QR_OK;
+}
+
 extern "C" int qr_render_async(qr_device_scene *s, void *frame_dev, void *stream)
 {
     if (s == nullptr || frame_dev == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
+    { const int rc = pt_rows_ok(s); if (rc != QR_OK) return rc; }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch<false>(s, frame_dev, nullptr, (hipStream_t)stream));
     return QR_OK;
@@ -548,6 +566,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
                                int iters, float *avg_ms, float *min_ms)
 {
     if (s == nullptr || frame_dev == nullptr || iters <= 0) return qr_fail(QR_ERR_ARG, "bad argument");
+    { const int rc = pt_rows_ok(s); if (rc != QR_OK) return rc; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
     double sum = 0.0; float mn = 1e30f;
@@ -627,6 +646,7 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
     if (s == nullptr || frame_host == nullptr) return qr_fail(QR_ERR_ARG, "null argument");
     const int w = s->fr.frm_w, h = s->fr.frm_h;
     const size_t bytes = (size_t)w * h * 4;
+    { const int rc = pt_rows_ok(s); if (rc != QR_OK) return rc; }
     HIP_TRY(hipSetDevice(s->device));
     HostPathCache &c = g_hpc;
     if (c.device != s->device || c.d_cap < bytes)
@@ -715,7 +735,7 @@ struct DropIn
     uint8_t *h_stage = nullptr; size_t h_cap = 0;
     void *d_frame = nullptr; size_t df_cap = 0;
     uint32_t *h_frame = nullptr; size_t hf_cap = 0;
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr; size_t n_counters = 0;
     hipStream_t sk = nullptr, sc = nullptr;
     hipStream_t sx[QR_DROPIN_BLOCKS] = {};     /* one launch stream per row block (sx[0] == sk): a block's tail overlaps the next block's bulk */
     hipEvent_t ev_up = nullptr;                 /* uploads of this call are on the device */
@@ -727,32 +747,75 @@ struct DropIn
 };
 static thread_local DropIn g_drop;
 
-static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_bytes)
+/* everything a DropIn holds on its device; the caller has made that device current */
+static void dropin_release(DropIn &c)
+{
+    (void)hipDeviceSynchronize();
+    for (int k = 1; k < QR_DROPIN_BLOCKS; k++) if (c.sx[k]) (void)hipStreamDestroy(c.sx[k]);
+    if (c.sk) (void)hipStreamDestroy(c.sk);
+    if (c.sc) (void)hipStreamDestroy(c.sc);
+    if (c.ev_up) (void)hipEventDestroy(c.ev_up);
+    for (int k = 0; k < QR_DROPIN_BLOCKS; k++) { if (c.ev_k[k]) (void)hipEventDestroy(c.ev_k[k]); if (c.ev_c[k]) (void)hipEventDestroy(c.ev_c[k]); }
+    (void)hipFree(c.d_blob); (void)hipFree(c.d_frame); (void)hipFree(c.d_counters); (void)hipFree(c.d_pt);
+    if (c.h_stage) (void)hipHostFree(c.h_stage);
+    if (c.h_frame) (void)hipHostFree(c.h_frame);
+    c.sk = c.sc = nullptr; c.ev_up = nullptr;
+    for (int k = 0; k < QR_DROPIN_BLOCKS; k++) { c.sx[k] = nullptr; c.ev_k[k] = nullptr; c.ev_c[k] = nullptr; }
+    c.d_blob = nullptr; c.d_cap = 0; c.h_stage = nullptr; c.h_cap = 0;
+    c.d_frame = nullptr; c.df_cap = 0; c.h_frame = nullptr; c.hf_cap = 0;
+    c.d_counters = nullptr; c.n_counters = 0;
+    c.d_pt = nullptr; c.pt_cap = 0;
+    c.resident = false;
+    c.device = -1;
+}
+
+/* streams, events: created together; on any failure nothing is kept (c.device stays -1, the next call starts over) */
+static int dropin_create(DropIn &c)
+{
+    HIP_TRY(hipStreamCreateWithFlags(&c.sk, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c.sc, hipStreamNonBlocking));
+    c.sx[0] = c.sk;
+    for (int k = 1; k < QR_DROPIN_BLOCKS; k++) HIP_TRY(hipStreamCreateWithFlags(&c.sx[k], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
+    for (int k = 0; k < QR_DROPIN_BLOCKS; k++)
+    {
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_c[k], hipEventDisableTiming));
+    }
+    return QR_OK;
+}
+
+static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_bytes, size_t n_sched)
 {
     if (c.device != dev)
     {
-        /* first call of this thread (or another device): everything is created once; buffers of a previous
-         * device are abandoned (the HIP runtime frees them with the context) */
+        /* first call of this thread, or another device: what the previous device held is released there first;
+         * c.device is only set once every stream and event exists, so a failure leaves no half-built state behind */
+        if (c.device >= 0) { if (hipSetDevice(c.device) == hipSuccess) dropin_release(c); c.device = -1; }
         int rc = pick_device(dev);
         if (rc != QR_OK) return rc;
-        c.d_blob = nullptr; c.d_cap = 0; c.h_stage = nullptr; c.h_cap = 0;
-        c.d_frame = nullptr; c.df_cap = 0; c.h_frame = nullptr; c.hf_cap = 0;
-        c.resident = false;
-        c.d_pt = nullptr; c.pt_cap = 0;
+        rc = dropin_create(c);
+        if (rc != QR_OK) { dropin_release(c); return rc; }
         c.device = dev;
-        HIP_TRY(hipStreamCreateWithFlags(&c.sk, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c.sc, hipStreamNonBlocking));
-        c.sx[0] = c.sk;
-        for (int k = 1; k < QR_DROPIN_BLOCKS; k++) HIP_TRY(hipStreamCreateWithFlags(&c.sx[k], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
-        for (int k = 0; k < QR_DROPIN_BLOCKS; k++)
-        {
-            HIP_TRY(hipEventCreateWithFlags(&c.ev_k[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c.ev_c[k], hipEventDisableTiming));
-        }
-        HIP_TRY(hipMalloc((void **)&c.d_counters, 32 * sizeof(unsigned long long)));
     }
     else HIP_TRY(hipSetDevice(dev));
+    {
+        /* counter block as qr_scene_upload_ex sizes it: 64 words (ray counts, QR_STATS slots 4..34), and per wave of the
+         * schedule QR_WT_SLOTS more in QR_WAVETIME builds */
+#ifdef QR_WAVETIME
+        const size_t need = 64 + QR_WT_SLOTS * n_sched;
+#else
+        const size_t need = 64; (void)n_sched;
+#endif
+        if (c.n_counters < need)
+        {
+            if (c.d_counters) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c.d_counters); }
+            c.d_counters = nullptr; c.n_counters = 0;
+            HIP_TRY(hipMalloc((void **)&c.d_counters, need * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(c.d_counters, 0, need * sizeof(unsigned long long)));
+            c.n_counters = need;
+        }
+    }
     if (c.d_cap < image_bytes)
     {
         if (c.d_blob) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c.d_blob); }
@@ -896,8 +959,10 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         E.assign(v.elm, v.elm + v.hdr->n_elm);
         T.assign(v.tiles, v.tiles + v.hdr->n_tiles);
         qr_frame frm = *v.frame;
-        /* QR_REBIN=1: the per-tile lists are rebuilt on the GPU from the camera list instead of taken from the engine
-         * (same frames; the engine may then run without its own tiling, RT_OPTS_TILING) */
+        /* QR_REBIN=1: the per-tile lists are rebuilt on the GPU from the camera list instead of taken from the engine (the
+         * engine may then run without its own tiling, RT_OPTS_TILING).  The frame is the engine's UNTILED picture: on most
+         * scenes that is also its tiled one, but where its screen tiling drops a surface from a tile that the surface does
+         * cover the two differ, so this is not the drop-in-exact mode */
         static const bool rebin = []() { const char *v = getenv("QR_REBIN"); return v && atoi(v) != 0; }();
         if (rebin)
         {
@@ -913,7 +978,7 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     const qr_frame &fr = c.prog.frm;
     const int w = fr.frm_w, h = fr.frm_h;
     const size_t frame_bytes = (size_t)w * h * 4;
-    rc = dropin_prepare(c, dev, c.prog.blob.size(), frame_bytes);
+    rc = dropin_prepare(c, dev, c.prog.blob.size(), frame_bytes, c.prog.n_sched);
     if (rc != QR_OK) return rc;
     if (!same)
     {
@@ -929,6 +994,13 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     {
         rc = dropin_pt_begin(c, s_inf, abi, fr, ptio, pt);
         if (rc != QR_OK) return rc;
+    }
+    else
+    {
+        /* FF_ini, tracer.cpp:1128-1132: every ray-traced frame zeroes the sample count in s_inf; rt_Scene::set_pton relies on
+         * it to restart the accumulation after it has reset the seed and colour planes (engine.cpp:3729-3745) */
+        float *pts_c = (float *)((uint8_t *)(uintptr_t)s_inf + (size_t)abi->quads * 0x130 + 0x100 * (size_t)(abi->pointer_bits / 32));
+        for (size_t l = 0; l < (size_t)abi->quads * 4; l++) pts_c[l] = 0.0f;
     }
 
     LaunchP lp = {};

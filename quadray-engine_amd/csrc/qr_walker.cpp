@@ -466,8 +466,8 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     uint64_t p_tiles = rd_ptr(a, inf, slot(15));
     int32_t  pt_on   = (int32_t)rd_cell(a, inf, slot(19));
 
-    /* path-tracer mode: a snapshot can be captured (emission included); rendering through qr_render0 stays refused
-     * there, because the engine's colour and seed planes live on the host */
+    /* path-tracer mode: the snapshot records it (emission included); qr_render0 then carries the engine's seed and
+     * colour planes to the device and back around the launches (qr_device.hip, dropin_pt_begin / _end) */
     w.pt = pt_on != 0;
     if (p_ctx == 0 || p_cam == 0) { err = "s_inf->ctx / cam is NULL"; return QR_ERR_ARG; }
     if (frm_w <= 0 || frm_h <= 0 || frm_w > 65536 || frm_h > 65536) { err = "bad frame size"; return QR_ERR_ARG; }

@@ -121,7 +121,12 @@ def test_gpu_drop_in_through_reference_engine():
 @pytest.mark.parametrize("args", [["-w", "160", "-h", "120", "--pt", "3"],
                                   ["-w", "200", "-h", "150", "--pt", "4", "--fsaa", "4", "--gamma", "--fresnel"],
                                   ["-w", "160", "-h", "120", "--pt", "3", "--threads", "4"],
-                                  ["-w", "96", "-h", "64", "--pt", "2", "--depth", "4"]])
+                                  ["-w", "96", "-h", "64", "--pt", "2", "--depth", "4"],
+                                  # path tracer on -> a frame -> off -> a ray-traced frame -> on again: the ray-traced frame must
+                                  # zero the sample count in s_inf (FF_ini, tracer.cpp:1128-1132) or the restarted accumulation
+                                  # weighs its first frame as the second
+                                  ["-w", "128", "-h", "96", "--pt", "3", "--pt-warm"],
+                                  ["-w", "128", "-h", "96", "--pt", "2", "--pt-warm", "--threads", "4", "--fsaa", "2"]])
 def test_gpu_drop_in_path_tracer_through_reference_engine(args):
     """Path-tracer mode through the drop-in boundary: the unmodified engine accumulates N frames with its own CPU SIMD
     backend in one process and, in another, with EVERY frame going through ref_shim.cpp -> qr_render0 (--shim): the
