@@ -12,6 +12,7 @@
  * trnode (1931-2151).  Pure host code: no HIP here, so the CPU test-suite exercises it on every fixture.
  */
 #include "qr_internal.h"
+#include "qr_sides.h"
 #include "qr_program.h"
 #include "qr_bounds.hpp"
 
@@ -201,6 +202,22 @@ struct ListFilter
     template <typename Pred>
     int filter(Pred keep)
     {
+        return filter_nodes([&](int i) {
+            const Node &nd = ch[i];
+            if (nd.head) return !nd.bounded || keep(nd.bound, true);
+            return keep(nd.bound, nd.bounded);
+        });
+    }
+
+    /* keep(i) by position in the chain: for an array element "may any member matter" (false prunes the array without
+     * visiting its members), for a surface "does it belong on the list".  A list that keeps everything IS the source list:
+     * its head is returned and nothing is allocated (per-surface copies of one global list are what makes the engine's
+     * lists grow with the square of the scene). */
+    template <typename Pred>
+    int filter_nodes(Pred keep)
+    {
+        const size_t e_mark = E.size();
+        bool dropped = false;
         struct Open { int idx; int out; int last; };
         std::vector<Open> open;
         int head = QR_NULL, tail = QR_NULL;
@@ -227,20 +244,22 @@ struct ListFilter
             const Node &nd = ch[i];
             if (nd.head)
             {
-                if (nd.bounded && !keep(nd.bound, true)) { i = nd.last + 1; continue; }      /* prune the array */
+                if (!keep(i)) { dropped = true; i = nd.last + 1; continue; }      /* prune the array */
                 open.push_back(Open{i, QR_NULL, nd.last});
                 i++;
                 continue;
             }
             const bool real = is_real(v.srf[nd.si]);
-            if (!real || keep(nd.bound, nd.bounded))
+            if (!real || keep(i))
             {
                 for (Open &o : open) if (o.out == QR_NULL) o.out = emit(ch[o.idx].e, QR_NULL);
                 emit(nd.e, E[nd.e].data);
             }
+            else dropped = true;
             i++;
         }
         close_until(n);
+        if (!dropped && n > 0) { E.resize(e_mark); return ch[0].e; }
         /* a list that keeps only a handful of surfaces does not need their bounding-volume elements (AR_ptr elements
          * only skip work, tracer.cpp:3955-4054): written flat it is a fraction of the cells.  Trnode elements stay. */
         int kept = 0;
@@ -1277,72 +1296,19 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
 #endif
 
 /*
- * Which sides of surface i a light at `lp` is entered on: 1 inner, 2 outer, 3 both.  This is NOT a cull in the engine
- * but part of its picture: with RT_OPTS_2SIDED its lsort (engine.cpp:2503-2533) asks bbox_side -> clip_side
- * (rtgeom.cpp:939-995) where the light stands relative to the surface -- surf_side (894-931: the sign of the quadric
- * form at the light's position, margin RT_CULL_THRESHOLD), convexity (surf_conc, 718-732), holes (surf_hole, 607-660:
- * axis clippers that cut, custom clippers) and the clip box (surf_cbox, 802-840) -- and the inside of a closed convex
- * shell never gets a light that stands outside, whether or not the shell casts a shadow.
+ * Per-side placement (qr_sides.cpp = the engine's bbox_side / clip_side): NOT a cull in the engine but part of its picture.
+ * Lights: with RT_OPTS_2SIDED its lsort (engine.cpp:2503-2533) enters a light on the outer and / or the inner light list by
+ * where it stands relative to the clipped surface, so the inside of a closed convex shell never gets a light that stands
+ * outside, whether or not the shell casts a shadow.  Surfaces: ssort (engine.cpp:2134-2450) puts every node on the outer
+ * and / or inner list of a surface whose material reflects or is not opaque; a convex shape is absent from its own outer
+ * list, a bowl's inside holds what the box test sees through its opening.  The engine's per-side lists are copies of its
+ * hierarchy per surface -- memory grows with the square of the scene (engine.cpp:2951-2956) -- so scenes with more than
+ * QR_SIDES_EXACT_MAX real surfaces keep ONE shared list for both sides of their quadrics (a superset of what the engine would
+ * place there; planes get the half-space filter below).
  */
-static int light_sides(const qr_scene_view &v, int i, const float lp[3])
-{
-    const float thr = 0.0001f;                                  /* RT_CULL_THRESHOLD, rtgeom.h:33 */
-    const qr_surface &s = v.srf[i];
-    float p[3] = { lp[0], lp[1], lp[2] };
-    if (s.trnode != QR_NULL)
-    {
-        /* node_tran 775-791: the position in the transform node's space */
-        const qr_surface &t = v.srf[s.trnode];
-        const float d[3] = { lp[0] - t.pos[0], lp[1] - t.pos[1], lp[2] - t.pos[2] };
-        p[0] = t.tci[0] * d[0] + t.tci[1] * d[1] + t.tci[2] * d[2];
-        p[1] = t.tcj[0] * d[0] + t.tcj[1] * d[1] + t.tcj[2] * d[2];
-        p[2] = t.tck[0] * d[0] + t.tck[1] * d[1] + t.tck[2] * d[2];
-    }
-    const bool own = s.trnode == i;
-    float loc[3];
-    for (int a = 0; a < 3; a++) loc[a] = own ? p[a] : p[a] - s.pos[a];
-    const int tag = s.srf_t[3];
-    float d;
-    if (tag == QR_TAG_PLANE)
-    {
-        const int k = (int)((s.axes >> 4) & 3);
-        d = ((s.axes >> 10) & 1) ? -loc[k] : loc[k];
-    }
-    else
-    {
-        /* the snapshot keeps half of the shape's linear coefficients (rt_Quadric::commit_fields, object.cpp:3059-3061) */
-        const float dcj = loc[0] * (s.scj[0] + s.scj[0]) + loc[1] * (s.scj[1] + s.scj[1]) + loc[2] * (s.scj[2] + s.scj[2]);
-        const float dci = loc[0] * loc[0] * s.sci[0] + loc[1] * loc[1] * s.sci[1] + loc[2] * loc[2] * s.sci[2];
-        d = dci - dcj - s.sci[3];
-    }
-    int c = d > thr ? 2 : (d >= -thr ? 0 : 1);
-    if (c == 0) return 3;
-    if (tag == QR_TAG_PLANE) return c;
-    const bool concave = tag == 3 || tag == 5 || tag == 7 || tag == 8;     /* cone, hyperboloid, hypercylinder, hyperparaboloid */
-    if (!concave && c == 1) return c;
-    int hole = (s.minmax_t & 63u) ? 1 : 0;
-    bool skip = false;
-    for (int e = s.clip; e != QR_NULL; e = v.elm[e].next)
-    {
-        const qr_elem &el = v.elm[e];
-        if (el.simd == QR_NULL) { skip = !skip; continue; }     /* accum marker */
-        if (el.kind == 2) continue;                             /* trnode element */
-        (void)skip;
-        hole |= 2;                                              /* any clipper other than the surface itself */
-        break;
-    }
-    if (hole == 0) return c;
-    if (hole & 2) return 3;
-    for (int a = 0; a < 3; a++)
-    {
-        const float off = own ? 0.0f : s.pos[a];
-        const float cmin = (s.minmax_t & (1u << a)) ? s.min[a] + off : -__builtin_inff();
-        const float cmax = (s.minmax_t & (1u << (3 + a))) ? s.max[a] + off : __builtin_inff();
-        /* outside the clip box or on its border (both with the margin): the other side shows through the opening */
-        if (p[a] - thr <= cmin || p[a] + thr >= cmax) return 3;
-    }
-    return c;
-}
+#ifndef QR_SIDES_EXACT_MAX
+#define QR_SIDES_EXACT_MAX 512
+#endif
 
 int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, std::string &err)
 {
@@ -1356,6 +1322,35 @@ int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, s
     std::vector<qr_elem> E(v.elm, v.elm + v.hdr->n_elm);
     std::vector<qr_surface> S(v.srf, v.srf + n_srf);
     ListFilter lf(v, bs, E, fr.clist);
+    QrSideGeom geom(v);
+    int exact_max = QR_SIDES_EXACT_MAX;
+    if (const char *e = getenv("QR_SIDES_EXACT_MAX")) exact_max = atoi(e);
+    const bool exact_sides = lf.n_real <= exact_max;
+    std::vector<uint8_t> mask(lf.ch.size());
+    /* boxes of the chain's array elements (transform nodes; bounding-volume nodes where the list has them: the engine drops
+     * them from a camera list when its screen tiling is on, engine.cpp:1711-1725) */
+    std::vector<int> head_box(lf.ch.size(), -1);
+    if (exact_sides)
+    {
+        std::vector<int> leaves;
+        for (size_t k = 0; k < lf.ch.size(); k++)
+        {
+            if (!lf.ch[k].head) continue;
+            leaves.clear();
+            for (int q = (int)k + 1; q <= lf.ch[k].last; q++)
+                if (!lf.ch[q].head && is_real(v.srf[lf.ch[q].si])) leaves.push_back(lf.ch[q].si);
+            const qr_surface &rec = v.srf[lf.ch[k].si];
+            int space = rec.srf_t[3] < 0 ? lf.ch[k].si : rec.trnode;          /* a transform node's box lives in its own space */
+            if (rec.srf_t[3] >= 0 && rec.trnode == QR_NULL && rec.sci[3] != 0.75f && !leaves.empty())
+            {
+                /* sphere form of a transform node's inner box (object.cpp:2268-2289): the box is in the members' space */
+                int t = v.srf[leaves[0]].trnode;
+                for (int m : leaves) if (v.srf[m].trnode != t) t = QR_NULL;
+                space = t;
+            }
+            head_box[k] = geom.add_array_box(leaves.data(), (int)leaves.size(), space);
+        }
+    }
 
     for (int i = 0; i < n_srf; i++)
     {
@@ -1365,7 +1360,35 @@ int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, s
         const bool s_bounded = sb.r < 1e18f;
         /* reflection / refraction lists per side */
         int side_list[2] = { fr.clist, fr.clist };
-        if (s.srf_t[0] == 1 && s.has_trm == 0)
+        if (exact_sides)
+        {
+            /* the walk of ssort / lsort over the hierarchy, engine.cpp:2222-2330, 2575-2680: a node's sides come from
+             * bbox_side -- unless an array above it was seen from one side only: then everything under that array goes where
+             * the array went, unasked; an array seen from no side (every corner within the margin of a plane) is not entered
+             * at all.  The same placement serves the surface lists and, below, the shadow list of each side's light entries */
+            int inherit_until = -1; uint8_t c = 3;
+            for (int k = 0; k < (int)lf.ch.size(); k++)
+            {
+                if (k > inherit_until)
+                {
+                    inherit_until = -1;
+                    const ListFilter::Node &nd = lf.ch[k];
+                    if (nd.head) c = (uint8_t)geom.side(head_box[k], i);
+                    else c = is_real(v.srf[nd.si]) ? (uint8_t)geom.side(nd.si, i) : (uint8_t)3;
+                    if (nd.head && c < 3) inherit_until = nd.last;
+                }
+                mask[k] = c;
+            }
+            /* surfaces whose material neither reflects nor lets light through keep the global list on both sides (no ray
+             * ever walks it, engine.cpp:2155-2176) */
+            if (geom.builds_side_lists(i))
+                for (int side = 0; side < 2; side++)
+                {
+                    const uint8_t bit = side == 0 ? 2 : 1;          /* side 0 = outer */
+                    side_list[side] = lf.filter_nodes([&](int k) { return (mask[k] & bit) != 0; });
+                }
+        }
+        else if (s.srf_t[0] == 1 && s.has_trm == 0)
         {
             const int k = (int)((s.axes >> 4) & 3);
             const double sg = ((s.axes >> 10) & 1) ? -1.0 : 1.0;
@@ -1380,43 +1403,35 @@ int qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, s
             }
         }
         s.lst[1] = side_list[0]; s.lst[3] = side_list[1];
-        /* light lists of the two sides, per-light shadow lists shared between them; which side a light is entered on is
-         * the engine's rule (light_sides above), not a cull */
+        /* light lists of the two sides; which side a light is entered on is the engine's rule (clip_side), not a cull */
         int l_head[2] = { QR_NULL, QR_NULL }, l_tail[2] = { QR_NULL, QR_NULL };
         for (int l = 0; l < n_lgt; l++)
         {
+            /* what may stand between the light and the surface (bbox_shad's role): the hull of the light's position and the
+             * surface's bounding sphere; an unbounded surface, or a light inside / next to that sphere, keeps everything */
+            const double sc[3] = { sb.c[0], sb.c[1], sb.c[2] };
+            const HullPred hp(v.lgt[l].pos, sc, s_bounded ? (double)sb.r : 1e30);
             int shadow = fr.clist;
-            if (s_bounded)
-            {
-                const double lp[3] = { v.lgt[l].pos[0], v.lgt[l].pos[1], v.lgt[l].pos[2] };
-                const double D[3] = { sb.c[0] - lp[0], sb.c[1] - lp[1], sb.c[2] - lp[2] };
-                const double D2 = D[0] * D[0] + D[1] * D[1] + D[2] * D[2], Dl = __builtin_sqrt(D2);
-                const double rho = Dl > 0.0 ? (double)sb.r / Dl : 2.0;
-                if (rho < 0.95)
-                {
-                    /* hull of the light position and the surface's sphere: at parameter tau in [0,1] along the axis a
-                     * sphere of radius tau r_s; a sphere (c, r_x) meets it iff min_tau |c - axis(tau)| - tau r_s <= r_x;
-                     * the minimum is at least d_min sqrt(1 - rho^2) - tc r_s with d_min the distance to the axis
-                     * segment and tc its parameter */
-                    const double shrink = __builtin_sqrt(1.0 - rho * rho);
-                    shadow = lf.filter([&](const BSphere &x, bool bounded) {
-                        if (!bounded) return true;
-                        const double P[3] = { x.c[0] - lp[0], x.c[1] - lp[1], x.c[2] - lp[2] };
-                        const double t = (P[0] * D[0] + P[1] * D[1] + P[2] * D[2]) / D2;
-                        const double tc = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-                        const double q[3] = { P[0] - tc * D[0], P[1] - tc * D[1], P[2] - tc * D[2] };
-                        const double dmin = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-                        const double xr = (double)x.r * 1.001 + 1e-3;
-                        if (t > 1.0 + ((double)sb.r + xr) / Dl + 1e-3) return false;        /* behind the surface */
-                        return dmin * shrink <= xr + tc * (double)sb.r * 1.001 + 1e-3;
-                    });
-                }
-            }
-            const int sides = light_sides(v, i, v.lgt[l].pos);
+            if (!exact_sides && !hp.all) shadow = lf.filter(hp);
+            const int sides = geom.clip_side(i, v.lgt[l].pos);
             for (int side = 0; side < 2; side++)
             {
-                if (!(sides & (side == 0 ? 2 : 1))) continue;
-                qr_elem c; c.simd = l; c.data = shadow; c.next = QR_NULL; c.kind = 0;
+                const uint8_t bit = side == 0 ? 2 : 1;
+                if (!(sides & bit)) continue;
+                /* the engine keeps one shadow list per side a light is entered on: what may cast a shadow (its bbox_shad; here
+                 * the hull predicate above) AND is placed on that side of the surface (lsort, engine.cpp:2590-2612) -- the
+                 * outer side of a convex shape never tests the shape itself */
+                int side_shadow = shadow;
+                if (exact_sides)
+                    side_shadow = lf.filter_nodes([&](int k) {
+                        if (!(mask[k] & bit)) return false;
+                        const ListFilter::Node &nd = lf.ch[k];
+                        if (!nd.head && !is_real(v.srf[nd.si])) return true;
+                        /* the engine's own box predicate, not a tighter or looser one of ours: where it misses a caster (its
+                         * corner / face / edge tests are not exhaustive) the reference's picture has no shadow there */
+                        return geom.shad(v.lgt[l].pos, nd.head ? head_box[k] : nd.si, i) != 0;
+                    });
+                qr_elem c; c.simd = l; c.data = side_shadow; c.next = QR_NULL; c.kind = 0;
                 E.push_back(c);
                 const int ix = (int)E.size() - 1;
                 if (l_tail[side] != QR_NULL) E[l_tail[side]].next = ix; else l_head[side] = ix;

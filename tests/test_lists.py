@@ -1,17 +1,33 @@
-"""Per-surface list building (qr_snapshot_build_lists_c: the role of the engine's ssort / lsort with bbox culling,
-engine.cpp:2134-2753).  Lists only cull: a snapshot whose shadow / reflection / light lists were rebuilt from its global
-list must give the reference's pixels.  CPU part: the pass is host code, the oracle renders its output."""
+"""Per-surface list building (qr_snapshot_build_lists_c: the role of the engine's ssort / lsort, engine.cpp:2134-2753, with
+the box predicates bbox_side / bbox_shad / clip_side of rtgeom.cpp restated in csrc/qr_sides.cpp).
+
+The engine's lists are part of its PICTURE, not a neutral cull (a convex shape is absent from the lists of its own outer
+side, a caster its corner / face / edge tests miss casts no shadow), so the bar is the engine's own lists: on snapshots
+that keep the scene's hierarchy in their global list (tests/golden/lists/, captured with screen tiling off,
+make_lists_golden.py) the pass must rebuild EVERY per-side surface list, light list and per-side shadow list of every
+surface with the same members, and the rebuilt snapshot must render to the reference's frame with ZERO differing pixels.
+CPU part: the pass is host code, the oracle renders its output."""
+import gzip
 import importlib.util
+import json
 import os
+import struct
 
 import numpy as np
 import pytest
 
-from conftest import ROOT, SMALL_CASES, load_blob, load_frame
+from conftest import GOLDEN, MANIFEST, ROOT, SMALL_CASES, load_blob, load_frame
 
-CPU_CASES = ["demo01_160", "demo01_160_gf_t5000", "demo02_160_gf_d3", "demo02_odd_33x17_aa4", "demo03_160", "test03_160",
-             "test09_160", "test12_160", "test13_160", "test16_160_noopt", "test18_160_gf_t4000",
-             "swarm_demo01_240", "swarm_demo03_200_t3000", "test11_160_j7"]
+with open(os.path.join(GOLDEN, "lists", "manifest.json")) as _f:
+    LISTS = json.load(_f)
+LIST_CASES = sorted(LISTS)
+SWARMS = [n for n in LIST_CASES if n.startswith("swarm_")]
+assert len(SWARMS) == 6
+
+
+def load_list_blob(name):
+    with open(os.path.join(GOLDEN, "lists", LISTS[name]["snapshot"]), "rb") as f:
+        return gzip.decompress(f.read())
 
 
 def _synth():
@@ -21,26 +37,76 @@ def _synth():
     return mod
 
 
-def _two_sided_slack(name):
-    """Pixels that may differ from the reference with rebuilt lists.  Light lists follow the engine's rule for the side a
-    light is entered on (light_sides in qr_compile.cpp = clip_side, rtgeom.cpp:939-995: equal to the engine's lists on
-    every surface side of the swarm fixtures).  What is left: the engine's per-side SURFACE lists of a quadric hold only
-    what its box predicates (bbox_side, rtgeom.cpp:1954-2128) place on that side of the clipped shape; the pass keeps the
-    whole list for quadrics, and in a crowd of interpenetrating open shells that is not the same picture (putting the
-    engine's inner-side list of one transparent bowl back restores the reference's pixel).  The stock scenes: 0 pixels;
-    the swarm fixtures: up to six of 19 200, hit ids equal."""
-    return 6 if name.startswith("swarm_") else 0
+class _Snap:
+    """the list structure of a snapshot (include/qr_scene.h)"""
+    def __init__(self, blob):
+        h = struct.unpack_from("<26I", blob, 0)
+        self.n_srf, self.n_elm = h[4], h[7]
+        self.srf = np.frombuffer(blob, dtype=np.int32, count=self.n_srf * 64, offset=h[11]).reshape(self.n_srf, 64)
+        self.elm = np.frombuffer(blob, dtype=np.int32, count=self.n_elm * 4, offset=h[14]).reshape(self.n_elm, 4)
+
+    def real(self, i):
+        return 0 <= int(self.srf[i, 37]) < 9
+
+    def chain(self, head):
+        out, e = [], int(head)
+        while e >= 0:
+            out.append((int(self.elm[e, 0]), int(self.elm[e, 1]))); e = int(self.elm[e, 2])
+        return out
+
+    def members(self, head):
+        return sorted(si for si, _ in self.chain(head) if self.real(si))
+
+    def lists_of(self, i):
+        """(outer surfaces, inner surfaces, {light: shadow casters} outer, the same inner)"""
+        l = [int(x) for x in self.srf[i, 44:48]]
+        return (self.members(l[1]), self.members(l[3]),
+                {lg: self.members(sh) for lg, sh in self.chain(l[0])}, {lg: self.members(sh) for lg, sh in self.chain(l[2])})
 
 
-@pytest.mark.parametrize("name", CPU_CASES)
+@pytest.mark.parametrize("name", LIST_CASES)
+def test_rebuilt_lists_are_the_engines_lists(qr, name):
+    """Every per-side surface list, every light list and every per-side shadow list the pass builds has the members of the
+    engine's own (the snapshot still carries them; the pass only reads the global list and the surfaces)."""
+    blob = load_list_blob(name)
+    ref, out = _Snap(blob), _Snap(qr.build_lists(blob))
+    n = 0
+    for i in range(ref.n_srf):
+        if not ref.real(i):
+            continue
+        assert out.lists_of(i) == ref.lists_of(i), f"surface {i}"
+        n += 1
+    assert n > 0
+
+
+@pytest.mark.parametrize("name", LIST_CASES)
 def test_rebuilt_lists_keep_the_reference_frame(qr, oracle, name):
-    blob = load_blob(name)
+    if MANIFEST[name]["w"] > 640:
+        pytest.skip("full-size case: rendered on the GPU only")
+    blob = load_list_blob(name)
     built = qr.build_lists(blob)
     frame, ids, _ = oracle.render(built, threads=8, want_ids=True)
-    assert int((frame != (load_frame(name) & 0xFFFFFF)).sum()) <= _two_sided_slack(name)
+    assert int((frame != (load_frame(name) & 0xFFFFFF)).sum()) == 0
     _, ids0, _ = oracle.render(blob, threads=8, want_ids=True)
     assert (ids == ids0).all()
     assert qr.program_stats(built).n_cells > 0           # and the result compiles into a verified device image
+
+
+def test_without_the_hierarchy_members_are_placed_one_by_one(qr, oracle):
+    """A camera list the engine's screen tiling has stripped of its bounding-volume elements (the ordinary fixtures of
+    tests/golden/) does not say which array a surface belongs to, so nothing can inherit an array's side: every member is
+    placed by its own box.  That is the same placement wherever a member's box agrees with its array's -- every ordinary
+    fixture renders to the reference's frame -- except for the one scene whose room walls sit in an array that lies on the
+    inner side of each wall: there the engine puts a wall on its own inner list (and coplanar neighbours with it), the
+    member-by-member placement does not; six pixels of round-off self-hits differ."""
+    bad = {}
+    for name in SMALL_CASES:
+        blob = load_blob(name)
+        frame, _, _ = oracle.render(qr.build_lists(blob), threads=8)
+        d = int((frame != (load_frame(name) & 0xFFFFFF)).sum())
+        if d:
+            bad[name] = d
+    assert bad == {"swarm_demo02_200_mix_gf": 6}
 
 
 def test_built_lists_replace_the_generators_own(qr, oracle):
@@ -100,8 +166,32 @@ def test_build_lists_rejects_snapshot_without_global_list(qr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", LIST_CASES)
+def test_gpu_rebuilt_lists_keep_pixels_and_hit_ids(qr, oracle, name):
+    """Zero slack: the rebuilt snapshot renders to the reference's frame (pixel for pixel; the 1920x1080 swarm by its hash)
+    with the hit ids and ray counts of the engine's own lists -- the lists have the same members."""
+    import torch
+    blob = load_list_blob(name)
+    base = qr.Scene(blob)
+    f0 = base.new_frame(); i0 = torch.full_like(f0, -2)
+    base.render(f0, ids=i0)
+    scn = qr.Scene(qr.build_lists(blob))
+    f1 = scn.new_frame(); i1 = torch.full_like(f1, -2)
+    scn.render(f1, ids=i1); torch.cuda.synchronize()
+    out = f1.cpu().numpy().view(np.uint32)
+    if "frame" in MANIFEST[name]:
+        assert int((out != (load_frame(name) & 0xFFFFFF)).sum()) == 0
+    assert oracle.frame_hash(out) == int(MANIFEST[name]["hash"], 16)
+    assert bool((f0 == f1).all()) and bool((i0 == i1).all())
+    _, c0 = base.render_count(); _, c1 = scn.render_count()
+    assert c1.as_dict() == c0.as_dict()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", SMALL_CASES)
-def test_gpu_rebuilt_lists_keep_pixels_and_hit_ids(qr, name):
+def test_gpu_rebuilt_lists_of_tiled_snapshots(qr, name):
+    """The ordinary fixtures (camera lists without the hierarchy, see test_without_the_hierarchy_...): same frames and hit
+    ids except the six pixels of the one scene named there."""
     import torch
     blob = load_blob(name)
     base = qr.Scene(blob)
@@ -110,9 +200,6 @@ def test_gpu_rebuilt_lists_keep_pixels_and_hit_ids(qr, name):
     scn = qr.Scene(qr.build_lists(blob))
     f1 = scn.new_frame(); i1 = torch.full_like(f1, -2)
     scn.render(f1, ids=i1); torch.cuda.synchronize()
-    assert int((f1.cpu().numpy().view(np.uint32) != (load_frame(name) & 0xFFFFFF)).sum()) <= _two_sided_slack(name)
+    d = int((f1.cpu().numpy().view(np.uint32) != (load_frame(name) & 0xFFFFFF)).sum())
+    assert d == (6 if name == "swarm_demo02_200_mix_gf" else 0)
     assert bool((i0 == i1).all())
-    _, c0 = base.render_count(); _, c1 = scn.render_count()
-    # shadow rays may be more (wider shadow lists never change a light's visibility test count, but a `--opts none`
-    # snapshot enters every light on both sides where the pass follows the 2-sided rule) or fewer: not compared
-    assert c1.primary == c0.primary and c1.reflect == c0.reflect and c1.refract == c0.refract

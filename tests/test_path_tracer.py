@@ -115,6 +115,19 @@ def test_gpu_path_tracer_is_deterministic_and_restartable(qr, oracle):
         scn.render_count()                                            # counting renders are refused in this mode
     with pytest.raises(qr.QrError):
         qr.MultiRender([(scn, scn.new_frame(), 0, scn.height)])()    # and so are multi-target launches
+    # a path-traced frame is one more sample of EVERY pixel: cut into row-range launches the sample count would advance
+    # once per launch and weigh the later ranges wrongly -- refused, and nothing is counted by the refused call
+    two = scn.new_frame(); scn.render(two); torch.cuda.synchronize()
+    for sel in ((scn.set_rows, (0, scn.height // 2)), (scn.set_rows, (0, scn.height, 1, 2)), (scn.set_tile_rows, (1, 2))):
+        sel[0](*sel[1])
+        with pytest.raises(qr.QrError):
+            scn.render(two)
+        with pytest.raises(qr.QrError):
+            scn.render_host()
+    scn.set_rows(0, scn.height)
+    scn.set_pt(True)
+    again = scn.new_frame(); scn.render(again); torch.cuda.synchronize()
+    assert (again.cpu().numpy() == one.cpu().numpy()).all()           # whole frames work as before
 
 
 @pytest.mark.gpu
