@@ -204,7 +204,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 {
 #ifdef QR_WAVETIME
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
-    qr_wt_groups[0] = 0; qr_wt_groups[1] = 0;
+    qr_wt_groups[0] = 0; qr_wt_groups[1] = 0; qr_wt_shadow = 0; qr_wt_cells[0] = qr_wt_cells[1] = qr_wt_cells[2] = qr_wt_cells[3] = 0;
     unsigned long long wt_mid = 0, wt_trav = 0, wt_shade = 0, wt_t0 = 0; u32 wt_push = 0;
 #endif
 #pragma clang diagnostic push
@@ -554,7 +554,8 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     {
         unsigned long long *o = counters + 64 + (size_t)gw * QR_WT_SLOTS;
         o[0] = wt_start; o[1] = wt_mid; o[2] = __builtin_amdgcn_s_memrealtime();
-        o[4] = ord; o[5] = qr_wt_groups[0]; o[6] = qr_wt_groups[1]; o[7] = wt_push; o[8] = wt_trav; o[9] = wt_shade; o[10] = 0;
+        o[4] = ord; o[5] = qr_wt_groups[0]; o[6] = qr_wt_groups[1]; o[7] = wt_push; o[8] = wt_trav; o[9] = wt_shade; o[10] = qr_wt_shadow;
+        o[11] = (unsigned long long)qr_wt_cells[0] | ((unsigned long long)qr_wt_cells[1] << 16) | ((unsigned long long)qr_wt_cells[2] << 32) | ((unsigned long long)qr_wt_cells[3] << 48);
         o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))
              | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) << 32)
              | ((unsigned long long)wt_push << 40);

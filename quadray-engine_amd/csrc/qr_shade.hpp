@@ -320,11 +320,17 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         if (QR_KNOB(2)) lm = false;
         if (QR_KNOB(1)) occ = false; else
         {
+#ifdef QR_WAVETIME
+            const unsigned long long wt_s0 = __builtin_amdgcn_s_memrealtime();
+#endif
             traverse<true, DIVK>(B, lm, coherent, sr, sh, occ
 #ifdef QR_STATS
                                   , cx.stats
 #endif
                                   );
+#ifdef QR_WAVETIME
+            if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_shadow += __builtin_amdgcn_s_memrealtime() - wt_s0;
+#endif
         }
         if (lm && !occ)
         {

@@ -340,6 +340,12 @@ __device__ __forceinline__ bool bv_hit(const V3 &ry, const V3 &df, float sci0, f
     return cle(0.0f, x3);
 }
 
+#ifdef QR_WAVETIME
+__shared__ unsigned qr_wt_groups[2];    /* list groups walked by this wave: nearest-hit, shadow (tools/gpu_wavetime.py) */
+__shared__ unsigned long long qr_wt_shadow;     /* 100 MHz ticks spent in shadow traversals */
+__shared__ unsigned qr_wt_cells[4];     /* packet walks of this wave: cells looked at (nearest-hit, shadow), cells solved (nearest-hit, shadow) */
+#endif
+
 /* per-lane state of one list walk */
 struct WalkState
 {
@@ -624,6 +630,9 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
              * new value), which keeps the cursor in an SGPR: with one readfirstlane here instead, it lived in a VGPR
              * and made the round trip v_mov / v_readfirstlane once per cell */
             QR_GUARD_POS(1, pos, head, return);
+#ifdef QR_WAVETIME
+            if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_cells[SHADOW ? 1 : 0]++;
+#endif
             c = *(const QR_CONST u32x8 *)(B + pos);
             if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
             const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
@@ -699,6 +708,9 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             {
                 SurfS s;
                 ld_surf(B, srf_off, s);
+#ifdef QR_WAVETIME
+                if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_cells[SHADOW ? 3 : 2]++;
+#endif
                 if (lane_of(on)) solve_cell<SHADOW, false>(B, op, srf_off, s, r, dd, w, h);
                 if (SHADOW)
                 {
@@ -1444,9 +1456,6 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
  * DIVK = false is the kernel instance for scenes without long hierarchies (every scene the reference engine
  * prepares): the per-lane walk is compiled out there, which is worth 4 % of instructions through register pressure.
  */
-#ifdef QR_WAVETIME
-__shared__ unsigned qr_wt_groups[2];    /* list groups walked by this wave: nearest-hit, shadow (tools/gpu_wavetime.py) */
-#endif
 template <bool SHADOW, bool DIVK>
 __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS

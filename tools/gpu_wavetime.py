@@ -42,8 +42,9 @@ for lo, hi in [(1, 1), (2, 3), (4, 8), (9, 1000)]:
 # the slowest waves: how long are their dependent chains?
 idx = np.argsort(-dur)[:8]
 for i in idx:
-    print(f"  slow wave: {dur[i]:7.1f} us start {st[i]:6.1f}  non-shadow walks {int(w[i,7])} cells {int(w[i,5])}  shadow walks {int(w[i,6])} cells {int(w[i,4])}"
-          f"  -> {dur[i]*1e3/max(1,int(w[i,4])+int(w[i,5])):.0f} ns per cell; us in traverse {int(w[i,8])/100:.1f}, shade {int(w[i,9])/100:.1f} of which shadow walks {int(w[i,10])/100:.1f}")
+    print(f"  slow wave: {dur[i]:7.1f} us start {st[i]:6.1f}  rounds {int(w[i,7])} nearest-hit groups {int(w[i,5])} shadow groups {int(w[i,6])}"
+          f"; us in traverse {int(w[i,8])/100:.1f}, shade {int(w[i,9])/100:.1f} of which shadow walks {int(w[i,10])/100:.1f};"
+          f" cells looked at {int(w[i,11]) & 0xFFFF} / shadow {(int(w[i,11]) >> 16) & 0xFFFF}, solved {(int(w[i,11]) >> 32) & 0xFFFF} / shadow {(int(w[i,11]) >> 48) & 0xFFFF}")
 # where the slowest waves are: footprint coordinates (schedule entry), and what their pixels see (primary hit ids)
 ids = torch.zeros((scn.height, scn.width), dtype=torch.int32, device="cuda")
 scn.render(f, ids=ids); torch.cuda.synchronize()
