@@ -712,14 +712,20 @@ struct Builder
             if (k.head == s.clip && k.trnode == s.trnode && k.cdef == cdef) return k.off;
         std::vector<CClip> prog;
         int redx = QR_NULL;
+        int group_last = -1;                /* index in prog of the last cell emitted for the open cached group */
         for (int e = s.clip; e != QR_NULL; e = E[e].next)
         {
             const qr_elem &el = E[e];
-            CClip c = {0, 0, 0, 0};
+            /* the cached trnode space of a group ends behind its last element (redx), whether or not that element emits a cell */
+            struct Closer { int &redx, &group_last; std::vector<CClip> &prog; int e;
+                            ~Closer() { if (group_last >= 0 && redx == QR_NULL) { prog[(size_t)group_last].op |= QR_CLF_LASTC; group_last = -1; } } } closer{redx, group_last, prog, e};
+            CClip c;
+            memset(&c, 0, sizeof(c));
             if (el.simd == QR_NULL)
             {
                 c.op = el.data > 0 ? QR_CLT_LEAVE : (QR_CLT_ENTER | (cdef ? QR_CLF_CDEF : 0u));
                 prog.push_back(c);
+                if (redx != QR_NULL) group_last = (int)prog.size() - 1;
                 continue;
             }
             const qr_surface &k = v.srf[el.simd];
@@ -735,7 +741,7 @@ struct Builder
             else if (el.simd == s.trnode)
             {
                 if (s.has_trm == 0) throw Fail{QR_ERR_UNSUP, "clipper trnode shared with an untransformed surface"};
-                c.op |= QR_CLT_TRSAME; redx = el.data; prog.push_back(c); continue;
+                c.op |= QR_CLT_TRSAME; redx = el.data; prog.push_back(c); group_last = (int)prog.size() - 1; if (e == redx) redx = QR_NULL; continue;
             }
             else
             {
@@ -745,7 +751,7 @@ struct Builder
                     if (redx != QR_NULL) throw Fail{QR_ERR_UNSUP, "untransformed array inside a clipper trnode"};
                     continue;
                 }
-                c.op |= QR_CLT_TRNODE; redx = el.data; prog.push_back(c); continue;
+                c.op |= QR_CLT_TRNODE; redx = el.data; prog.push_back(c); group_last = (int)prog.size() - 1; if (e == redx) redx = QR_NULL; continue;
             }
             const int ckind = k.srf_t[2];
             if (ckind == 0) continue;                   /* no clip function: no effect */
@@ -756,11 +762,22 @@ struct Builder
             const uint32_t ak = (k.axes >> 4) & 3u;
             if (ak == 0) c.op |= QR_CLF_KX; else if (ak == 1) c.op |= QR_CLF_KY;
             if ((k.axes >> 10) & 1u) c.op |= QR_CLF_SGNK;
+            if (ckind == 1 && mode != QR_CLF_OWN && ak <= 2)
+            {
+                /* fast plane cell: the plane's position along its axis with the sign folded in (qr_program.h) */
+                c.op |= QR_CLF_FASTPL;
+                const float val = (c.op & QR_CLF_SGNK) ? -k.pos[ak] : k.pos[ak];
+                memcpy(&c.aux, &val, 4);
+                c.sgn = (c.op & QR_CLF_SGNK) ? 0x80000000u : 0u;
+                c.mx = ak == 0 ? 0xFFFFFFFFu : 0u; c.my = ak == 1 ? 0xFFFFFFFFu : 0u; c.mz = ak == 2 ? 0xFFFFFFFFu : 0u;
+            }
             prog.push_back(c);
+            if (mode == QR_CLF_CACHED) group_last = (int)prog.size() - 1;
         }
-        CClip endc = {0, 0, 0, 0};
+        CClip endc;
+        memset(&endc, 0, sizeof(endc));
         prog.push_back(endc);
-        const uint32_t off = alloc(prog.size() * sizeof(CClip), 16);
+        const uint32_t off = alloc(prog.size() * sizeof(CClip), 32);
         memcpy(at<CClip>(off), prog.data(), prog.size() * sizeof(CClip));
         clip_memo.push_back(ClipKey{s.clip, s.trnode, cdef, off});
         st.n_clip_cells += (uint32_t)prog.size() - 1;
@@ -1189,17 +1206,31 @@ int qr_program_verify(const QrProgram &p, std::string &err)
         if (!in_arr(d->trn, p.off_srf, p.n_srf, sizeof(DSurf))) return bad("trnode offset");
         if (d->clip != 0)
         {
-            if ((d->clip & 15) || d->clip < p.off_lists) return bad("clipper program offset");
-            for (uint32_t o = d->clip;; o += 16)
+            if ((d->clip & 31) || d->clip < p.off_lists) return bad("clipper program offset");
+            bool in_group = false;
+            for (uint32_t o = d->clip;; o += (uint32_t)sizeof(CClip))
             {
-                if ((size_t)o + 16 > limit) return bad("clipper program runs off the image");
+                if ((size_t)o + sizeof(CClip) > limit) return bad("clipper program runs off the image");
                 const CClip *c = (const CClip *)(b.data() + o);
-                if (c->op == 0) break;
+                if (c->op == 0) { if (in_group) return bad("clipper program ends inside a trnode group"); break; }
                 const uint32_t t = c->op & QR_CLT_MASK;
                 if (t == 0 || (t & (t - 1)) != 0) return bad("bad clipper opcode");
                 if (t != QR_CLT_ENTER && t != QR_CLT_LEAVE && (!in_arr(c->srf, p.off_srf, p.n_srf, sizeof(DSurf)) || c->srf == p.off_srf + p.n_srf * (uint32_t)sizeof(DSurf))) return bad("clipper surface offset");
                 if ((c->op & QR_CLF_KX) && (c->op & QR_CLF_KY)) return bad("bad clipper axis");
                 if ((c->op & QR_CLF_CACHED) && (c->op & QR_CLF_OWN)) return bad("bad clipper transform mode");
+                /* the cached trnode space: opened by a trnode cell, closed behind the cell flagged QR_CLF_LASTC; cached cells
+                 * only inside, fast plane cells with one axis mask and a consistent sign */
+                if (t == QR_CLT_TRNODE || t == QR_CLT_TRSAME) in_group = true;
+                else if ((c->op & QR_CLF_CACHED) && !in_group) return bad("cached clipper cell outside a trnode group");
+                else if (!(c->op & QR_CLF_CACHED) && in_group && t != QR_CLT_ENTER && t != QR_CLT_LEAVE) return bad("world-space clipper cell inside a trnode group");
+                if (c->op & QR_CLF_LASTC) { if (!in_group) return bad("group end flag outside a group"); in_group = false; }
+                if (c->op & QR_CLF_FASTPL)
+                {
+                    const uint32_t ones = (c->mx == 0xFFFFFFFFu) + (c->my == 0xFFFFFFFFu) + (c->mz == 0xFFFFFFFFu);
+                    const uint32_t zeros = (c->mx == 0u) + (c->my == 0u) + (c->mz == 0u);
+                    if (t != QR_CLT_PLANE || (c->op & QR_CLF_OWN) || ones != 1 || zeros != 2) return bad("fast plane cell");
+                    if (c->sgn != ((c->op & QR_CLF_SGNK) ? 0x80000000u : 0u)) return bad("fast plane cell sign");
+                }
             }
         }
         for (int k = 0; k < 2; k++)

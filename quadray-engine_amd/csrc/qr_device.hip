@@ -538,6 +538,19 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
+#ifdef QR_PROF
+    {
+        unsigned long long pf[48];
+        HIP_TRY(hipMemcpyFromSymbol(pf, HIP_SYMBOL(qr_prof), sizeof(pf)));
+        static const char *nm[48] = { "candidates through clip()", "clipper programs run", "clipper cells", "  fast plane cells", "  trnode / trsame cells",
+            "  generic plane tests", "  quadric tests", "", "solve: plane cells", "solve: quadric cells", "solve: two-plane cells", "solve in shadow walks", "solve in nearest-hit walks",
+            "solve with own / cached transform", "solve with conic fix", "", "cells loaded by packet walks", "  culled by their sphere", "shadow packet walks", "nearest-hit packet walks",
+            "trnode cells", "bounding-volume cells", "", "", "shade() calls", "light rounds", "solves without any accepted hit", "  of them planes", "  of them without a candidate root" };
+        for (int i = 0; i < 29; i++) if (nm[i][0]) fprintf(stderr, "QR_PROF %-36s %llu\n", nm[i], pf[i]);
+        unsigned long long z[48] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(qr_prof), z, sizeof(z)));
+    }
+#endif
 #ifdef QR_STATS
     {
         unsigned long long st[32];

@@ -75,6 +75,17 @@
 typedef uint32_t u32;
 #define QR_SMASK 0x80000000u
 
+/* -DQR_PROF builds: wave-level event counters in a device global, printed by qr_render_count (where does a frame's instruction
+ * budget go: tools/gpu_prof.py) */
+#ifdef QR_PROF
+__device__ unsigned long long qr_prof[48];
+#define QR_PROF_HIT(i) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], 1ull); } while (0)
+#define QR_PROF_ADD(i, n) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], (unsigned long long)(n)); } while (0)
+#else
+#define QR_PROF_HIT(i) do { } while (0)
+#define QR_PROF_ADD(i, n) do { } while (0)
+#endif
+
 /* what a launch needs besides the scene image: kernel arguments */
 struct LaunchP
 {

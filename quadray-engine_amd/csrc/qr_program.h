@@ -121,11 +121,14 @@ struct CDda                     /* 64 B, immediately in front of the list progra
 
 /* ---- clipper programs (custom clipping, tracer.cpp:1931-2151) ------------------------------------------- */
 
-struct CClip                    /* 16 B */
+struct CClip                    /* 32 B: one s_load_dwordx8 per clipper */
 {
     uint32_t op;                /* QR_CL_* | flags                                                        */
     uint32_t srf;               /* byte offset of the clipper's DSurf                                     */
-    uint32_t aux;               /* spare                                                                  */
+    uint32_t aux;               /* fast plane cell: the plane's position along its axis, sign folded in (float) */
+    uint32_t sgn;               /* fast plane cell: 0x80000000 when the axis is negated, else 0           */
+    uint32_t mx, my, mz;        /* fast plane cell: all-ones for the plane's axis, 0 for the others: the component is
+                                 * (x & mx) | (y & my) | (z & mz), no decoding                              */
     uint32_t pad;
 };
 /* op == 0 ends the program; one type bit each */
@@ -145,6 +148,16 @@ struct CClip                    /* 16 B */
 #define QR_CLF_KY      (1u << 12)
 #define QR_CLF_SGNK    (1u << 13)
 #define QR_CLF_CDEF    (1u << 14)   /* ENTER: the owner's c_def mask is all ones                          */
+/*
+ * Fast plane cell (ours): a plane clipper that reads the hit as it stands -- in world space, or in the trnode space the
+ * cells before it have put it into (QR_CLF_CACHED) -- without a transform of its own.  The reference keeps
+ * f = +-(p_k - pos_k) <= 0 (MINUS_OUTER) or >= 0 (MINUS_INNER; APPLY_CLIP, tracer.cpp:488-496, PL_clp 4198-4208).  A
+ * rounded difference of two floats has the sign of the exact one, so with a = +-p_k and aux = +-pos_k (the sign folded
+ * in here) the tests are a <= aux and !(a < aux): one compare, no subtraction, no load of the clipper's record -- the
+ * same decisions bit for bit (NaN: false / true, as cle / cge).  `aux` holds the float.
+ */
+#define QR_CLF_FASTPL  (1u << 15)
+#define QR_CLF_LASTC   (1u << 16)   /* the cached trnode space ends behind this cell: fast plane cells read the world hit again */
 
 /* ---- light lists ----------------------------------------------------------------------------------------- */
 

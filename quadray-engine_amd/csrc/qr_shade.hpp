@@ -273,9 +273,11 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         }
     }
 
+    QR_PROF_HIT(24);                    /* shade() calls */
     /* lights, 2758-3156: wave-wide loop, per-lane light-list entries */
     while (any_lane(le != 0))
     {
+        QR_PROF_HIT(25);                /* light rounds */
         const bool has = le != 0;
         const CLight cl = *(const CLight *)(G + le);            /* lanes without a light read the header: harmless */
         const qr_light *__restrict__ lg = (const qr_light *)(G + (has ? (cl.lgt & ~QR_CLIGHT_LAST) : 0u));

@@ -152,6 +152,7 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
                                                     const ClipIn<DIV> &ci, float t, int side, typename MK<DIV>::T m, V3 &loc)
 {
     typedef MK<DIV> K;
+    QR_PROF_HIT(0);                     /* candidates through clip() */
     /* the opcode is re-read through an opaque copy: otherwise everything that only depends on it (the whole
      * axis decode of the conic fix, every flag as a 64-bit mask) is hoisted in front of the candidate loop and
      * paid by every cell */
@@ -249,73 +250,104 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
     if constexpr (DIV) run_clip = (op & QR_OPF_CLIP) && m; else run_clip = (op & QR_OPF_CLIP) && m != 0;
     if constexpr (!DIV || CLIPL) if (run_clip)
     {
+        QR_PROF_HIT(1);                 /* clipper programs run */
         typename K::T c_acc = K::none();
         V3 cxyz = {0.0f, 0.0f, 0.0f};                   /* the hit in the cached clipper trnode's space */
+        V3 pt = hit;                                    /* what a fast plane cell reads: the world hit, or cxyz while a trnode group lasts */
         u32 cp = s.clip;
         for (;;)
         {
             if constexpr (!DIV) cp = __builtin_amdgcn_readfirstlane(cp);
-            const u32x2 cc = *(const QR_CONST u32x2 *)(B + cp);
-            cp += 16;
-            const u32 cop = cc.x;
+            const u32x8 cc = *(const QR_CONST u32x8 *)(B + cp);
+            cp += (u32)sizeof(CClip);
+            const u32 cop = cc.s0;
             if (cop == 0) break;
-            if (cop & (QR_CLT_ENTER | QR_CLT_LEAVE))
+            QR_PROF_HIT(2);             /* clipper cells */
+            if (cop & QR_CLF_FASTPL)
+            {
+                QR_PROF_HIT(3);
+                /* a plane that reads the hit as it stands: the component by the cell's axis masks, the sign folded in, one
+                 * compare against the plane's position -- the decisions of +-(p_k - pos_k) <= 0 / >= 0 (qr_program.h) */
+                u32 t = f2u(pt.x) & cc.s4;
+                t = (f2u(pt.y) & cc.s5) | t;
+                t = (f2u(pt.z) & cc.s6) | t;
+                const float a = u2f(t ^ cc.s3), val = u2f(cc.s2);
+                const typename K::T keep_le = K::of(cle(a, val)), keep_ge = K::of(cge(a, val));
+                m = m & ((cop & QR_CLF_INNER) ? keep_ge : keep_le);
+            }
+            else if (cop & (QR_CLT_ENTER | QR_CLT_LEAVE))
             {
                 if (cop & QR_CLT_ENTER) { c_acc = m; m = (cop & QR_CLF_CDEF) ? K::inv(K::none()) : K::none(); }
                 else m = K::inv(m) & c_acc;
-                continue;
-            }
-            const u32 koff = cc.y;
-            const u32x4 k0 = *(const QR_CONST u32x4 *)(B + koff);
-            const float kp0 = u2f(k0.x), kp1 = u2f(k0.y), kp2 = u2f(k0.z);
-            if (cop & QR_CLT_TRSAME)
-            {
-                /* the clipper trnode is the surface's own: its local hit + pos is the hit in that space */
-                cxyz.x = x4 + s.pos0; cxyz.y = x5 + s.pos1; cxyz.z = x6 + s.pos2;
-                continue;
-            }
-            V3 cv;
-            if (cop & QR_CLF_CACHED)
-            {
-                cv.x = cxyz.x - kp0; cv.y = cxyz.y - kp1; cv.z = cxyz.z - kp2;
             }
             else
             {
-                V3 d;
-                d.x = hit.x - kp0; d.y = hit.y - kp1; d.z = hit.z - kp2;
-                if (cop & QR_CLT_TRNODE) { cxyz = xform(B, koff, (cop & QR_CLF_FULLM) != 0, d); continue; }
-                cv = (cop & QR_CLF_OWN) ? xform(B, koff, (cop & QR_CLF_FULLM) != 0, d) : d;
-            }
-            float f4;
-            if (cop & QR_CLT_PLANE)
-            {
-                f4 = fxor(axis3(cv, (cop & QR_CLF_KX) != 0, (cop & QR_CLF_KY) != 0), (cop & QR_CLF_SGNK) ? QR_SMASK : 0u);
-            }
-            else
-            {
-                const u32x4 k1 = *(const QR_CONST u32x4 *)(B + koff + 48);
-                const float ks0 = u2f(k1.x), ks1 = u2f(k1.y), ks2 = u2f(k1.z), ks3 = u2f(k1.w);
-                float f5, f6;
-                if (cop & QR_CLT_QUADJ)
+                const u32 koff = cc.s1;
+                const u32x4 k0 = *(const QR_CONST u32x4 *)(B + koff);
+                const float kp0 = u2f(k0.x), kp1 = u2f(k0.y), kp2 = u2f(k0.z);
+                if (cop & (QR_CLT_TRSAME | QR_CLT_TRNODE))
                 {
-                    const u32x4 k2 = *(const QR_CONST u32x4 *)(B + koff + 64);
-                    float f1, f2, f3;
-                    f4 = cv.x; f1 = u2f(k2.x); f1 = f1 + f1; f1 = f1 * f4;
-                    f4 = f4 * f4; f4 = f4 * ks0; f4 = f4 - f1;
-                    f5 = cv.y; f2 = u2f(k2.y); f2 = f2 + f2; f2 = f2 * f5;
-                    f5 = f5 * f5; f5 = f5 * ks1; f5 = f5 - f2;
-                    f6 = cv.z; f3 = u2f(k2.z); f3 = f3 + f3; f3 = f3 * f6;
-                    f6 = f6 * f6; f6 = f6 * ks2; f6 = f6 - f3;
+                    QR_PROF_HIT(4);
+                    if (cop & QR_CLT_TRSAME)
+                    {
+                        /* the clipper trnode is the surface's own: its local hit + pos is the hit in that space */
+                        cxyz.x = x4 + s.pos0; cxyz.y = x5 + s.pos1; cxyz.z = x6 + s.pos2;
+                    }
+                    else
+                    {
+                        V3 d;
+                        d.x = hit.x - kp0; d.y = hit.y - kp1; d.z = hit.z - kp2;
+                        cxyz = xform(B, koff, (cop & QR_CLF_FULLM) != 0, d);
+                    }
+                    pt = cxyz;
                 }
                 else
                 {
-                    f4 = cv.x; f4 = f4 * f4; f4 = f4 * ks0;
-                    f5 = cv.y; f5 = f5 * f5; f5 = f5 * ks1;
-                    f6 = cv.z; f6 = f6 * f6; f6 = f6 * ks2;
+                    V3 cv;
+                    if (cop & QR_CLF_CACHED)
+                    {
+                        cv.x = cxyz.x - kp0; cv.y = cxyz.y - kp1; cv.z = cxyz.z - kp2;
+                    }
+                    else
+                    {
+                        V3 d;
+                        d.x = hit.x - kp0; d.y = hit.y - kp1; d.z = hit.z - kp2;
+                        cv = (cop & QR_CLF_OWN) ? xform(B, koff, (cop & QR_CLF_FULLM) != 0, d) : d;
+                    }
+                    float f4;
+                    QR_PROF_HIT((cop & QR_CLT_PLANE) ? 5 : 6);
+                    if (cop & QR_CLT_PLANE)
+                    {
+                        f4 = fxor(axis3(cv, (cop & QR_CLF_KX) != 0, (cop & QR_CLF_KY) != 0), (cop & QR_CLF_SGNK) ? QR_SMASK : 0u);
+                    }
+                    else
+                    {
+                        const u32x4 k1 = *(const QR_CONST u32x4 *)(B + koff + 48);
+                        const float ks0 = u2f(k1.x), ks1 = u2f(k1.y), ks2 = u2f(k1.z), ks3 = u2f(k1.w);
+                        float f5, f6;
+                        if (cop & QR_CLT_QUADJ)
+                        {
+                            const u32x4 k2 = *(const QR_CONST u32x4 *)(B + koff + 64);
+                            float f1, f2, f3;
+                            f4 = cv.x; f1 = u2f(k2.x); f1 = f1 + f1; f1 = f1 * f4;
+                            f4 = f4 * f4; f4 = f4 * ks0; f4 = f4 - f1;
+                            f5 = cv.y; f2 = u2f(k2.y); f2 = f2 + f2; f2 = f2 * f5;
+                            f5 = f5 * f5; f5 = f5 * ks1; f5 = f5 - f2;
+                            f6 = cv.z; f3 = u2f(k2.z); f3 = f3 + f3; f3 = f3 * f6;
+                            f6 = f6 * f6; f6 = f6 * ks2; f6 = f6 - f3;
+                        }
+                        else
+                        {
+                            f4 = cv.x; f4 = f4 * f4; f4 = f4 * ks0;
+                            f5 = cv.y; f5 = f5 * f5; f5 = f5 * ks1;
+                            f6 = cv.z; f6 = f6 * f6; f6 = f6 * ks2;
+                        }
+                        f4 = f4 - ks3; f4 = f4 + f5; f4 = f4 + f6;
+                    }
+                    m = m & ((cop & QR_CLF_INNER) ? K::of(cge(f4, 0.0f)) : K::of(cle(f4, 0.0f)));
                 }
-                f4 = f4 - ks3; f4 = f4 + f5; f4 = f4 + f6;
             }
-            m = m & ((cop & QR_CLF_INNER) ? K::of(cge(f4, 0.0f)) : K::of(cle(f4, 0.0f)));
+            if (cop & QR_CLF_LASTC) pt = hit;           /* the trnode group ends here */
         }
     }
     return m;
@@ -414,6 +446,10 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
         mask_t cm0 = K::none(), cm1 = K::none();
         int   ncand = 0;
 
+        QR_PROF_HIT((op & QR_OPT_PLANE) ? 8 : ((op & QR_OPT_QUADRIC) ? 9 : 10));
+        QR_PROF_HIT(SHADOW ? 11 : 12);
+        if (op & (QR_OPF_OWN | QR_OPF_CACHED)) QR_PROF_HIT(13);
+        if (op & QR_OPF_CONIC) QR_PROF_HIT(14);
         if (op & QR_OPT_PLANE)
         {
             /* PL_ptr 4062-4136 */
@@ -582,6 +618,7 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
                 }
             }
         }
+        if (!K::any(done)) { QR_PROF_HIT(26); if (op & QR_OPT_PLANE) QR_PROF_HIT(27); if (ncand == 0) QR_PROF_HIT(28); }      /* nobody hit anything */
     }
         }
 
@@ -607,6 +644,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
     const float dde = dd * 1e-5f;
     w.tbd = w.tbuf * dd;
     u32 pos = __builtin_amdgcn_readfirstlane(head);
+    QR_PROF_HIT(SHADOW ? 18 : 19);      /* packet walks */
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0, st_skip = 0;
 #endif
@@ -634,6 +672,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_cells[SHADOW ? 1 : 0]++;
 #endif
             c = *(const QR_CONST u32x8 *)(B + pos);
+            QR_PROF_HIT(16);            /* cells loaded by packet walks */
             if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
             const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
             const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
@@ -647,6 +686,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             st_iter++; st_lanes += __popcll(LM(w.resume <= pos));
 #endif
             if (need != 0) break;
+            QR_PROF_HIT(17);            /* culled without looking at the surface */
 #ifdef QR_STATS
             st_skip++;
 #endif
@@ -678,6 +718,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
         {
             if (op & QR_OPT_TRNODE)
             {
+                QR_PROF_HIT(20);
                 /* array element with a transform: diff and ray in its space, cached for the surfaces behind it */
                 if (lane_of(on))
                 {
@@ -691,6 +732,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             else if (op & QR_OPT_BV)
             {
                 /* AR_ptr 3955-4054; the volume travels with the cell (CBvExt) */
+                QR_PROF_HIT(21);
                 next = pos + 64;
                 const u32x8 x = *(const QR_CONST u32x8 *)(B + pos + 32);
                 if (lane_of(on & ~far))
