@@ -18,9 +18,12 @@ struct BBox { bool valid; double p[8][3]; };     /* world-space corners of the (
 
 static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
 {
-    if (box) box->valid = false;
     const double INF = 1e300;
-    BSphere out = { {0.0f, 0.0f, 0.0f}, __builtin_inff() };
+    BSphere out;
+    out.c[0] = out.c[1] = out.c[2] = 0.0f; out.r = __builtin_inff();
+    BBox own_box;
+    if (box == nullptr) box = &own_box;          /* the corners also give the axis-aligned box */
+    box->valid = false;
     const qr_surface &q = v.srf[i];
     if (q.srf_t[3] < 0 || q.srf_t[3] >= QR_TAG_SURFACE_MAX) return out;
     double lo[3], hi[3];
@@ -152,6 +155,14 @@ static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
     double cl[3], r2 = 0.0;
     for (int k = 0; k < 3; k++) { cl[k] = 0.5 * (lo[k] + hi[k]); const double h = 0.5 * (hi[k] - lo[k]); r2 += h * h; }
     double rl = __builtin_sqrt(r2);
+    if (solver == 2 && q.scj[0] == 0.0f && q.scj[1] == 0.0f && q.scj[2] == 0.0f && q.sci[0] > 0.0f && q.sci[1] > 0.0f && q.sci[2] > 0.0f && q.sci[3] > 0.0f)
+    {
+        /* a closed ellipsoid about the local origin: the sphere of its largest half-axis holds it -- for a ball that is the
+         * ball itself, where the box's circumsphere is sqrt(3) times too wide */
+        const double smin = q.sci[0] < q.sci[1] ? (q.sci[0] < q.sci[2] ? q.sci[0] : q.sci[2]) : (q.sci[1] < q.sci[2] ? q.sci[1] : q.sci[2]);
+        const double re = __builtin_sqrt((double)q.sci[3] / smin) * 1.0005 + 1e-4;
+        if (re < rl) { rl = re; cl[0] = cl[1] = cl[2] = 0.0; }
+    }
     double cw[3];
     if (q.has_trm == 0)
     {
@@ -209,6 +220,18 @@ static BSphere bound_sphere(const qr_scene_view &v, int i, BBox *box = nullptr)
     if (!(r < 1e30)) return out;
     for (int k = 0; k < 3; k++) { if (!(cw[k] > -1e30 && cw[k] < 1e30)) return out; out.c[k] = (float)cw[k]; }
     out.r = (float)r * 1.0001f + 1e-6f;
+    if (box->valid)
+    {
+        /* axis-aligned box of the corners, inflated like the sphere (relative + absolute, then outward-rounded to float) */
+        for (int k = 0; k < 3; k++)
+        {
+            double mn = box->p[0][k], mx = box->p[0][k];
+            for (int c = 1; c < 8; c++) { if (box->p[c][k] < mn) mn = box->p[c][k]; if (box->p[c][k] > mx) mx = box->p[c][k]; }
+            const double pad = 2e-3 + 1e-3 * (mx - mn) + 1e-5 * ((mn < 0 ? -mn : mn) + (mx < 0 ? -mx : mx));
+            out.lo[k] = __builtin_nextafterf((float)(mn - pad), -__builtin_inff());
+            out.hi[k] = __builtin_nextafterf((float)(mx + pad), __builtin_inff());
+        }
+    }
     return out;
 }
 

@@ -344,6 +344,9 @@ struct Builder
     std::vector<BSphere> arr_sphere;
     QrProgramStats st = {};
     bool any_long = false;
+    bool box_ok = false;                    /* every list is short: cull cells may carry boxes (QR_OPF_BOX) */
+    bool any_box = false;
+    float box_pad = 0.0f;
 
     Builder(const qr_scene_view &v_, const std::vector<qr_elem> &E_, const std::vector<BSphere> &bs_, int cm, std::vector<uint8_t> &b)
         : v(v_), E(E_), bs(bs_), cull_mode(cm), blob(b), n_srf((int)v_.hdr->n_srf), n_elm((int)E_.size())
@@ -383,6 +386,8 @@ struct Builder
         }
         const int n = (int)ch.size();
         lo_after.assign((size_t)n, QR_NULL); lo_self.assign((size_t)n, QR_NULL);
+        /* box cull cells (QR_OPF_BOX) only in images whose lists are all short: the packet-walk kernel instance serves them */
+        const bool list_boxes = box_ok;
         int local_obj = QR_NULL;
         for (int i = 0; i < n; i++)
         {
@@ -437,7 +442,18 @@ struct Builder
                 if (s.conic != 0) op |= QR_OPF_CONIC;
                 const bool open_shape = s.srf_t[0] == 1 || !(s.sci[0] > 0.0f && s.sci[1] > 0.0f && s.sci[2] > 0.0f);
                 const bool want = cull_mode >= 3 || (cull_mode == 2 && open_shape) || (cull_mode == 1 && s.srf_t[0] == 1);
-                if (want && bs[el.simd].r < 1e18f) op |= QR_OPF_CULL;
+                if (want && bs[el.simd].r < 1e18f)
+                {
+                    op |= QR_OPF_CULL;
+                    /* box or sphere: whichever shows the smaller silhouette on average (a convex body's mean projected area
+                     * is a quarter of its surface) */
+                    const BSphere &bb = bs[el.simd];
+                    if (list_boxes && bb.lo[0] <= bb.hi[0])
+                    {
+                        const double a = (double)bb.hi[0] - bb.lo[0], b = (double)bb.hi[1] - bb.lo[1], c = (double)bb.hi[2] - bb.lo[2];
+                        if (0.5 * (a * b + b * c + c * a) < 0.8 * 3.14159265358979 * (double)bb.r * bb.r) { op |= QR_OPF_BOX; any_box = true; }
+                    }
+                }
             }
             t.op = op;
             lo_after[i] = local_obj;
@@ -548,7 +564,14 @@ struct Builder
             if (c.op & QR_OPT_BV) c.end = off + (uint32_t)emit_idx[ch[i].last + 1] * (uint32_t)sizeof(CCell);
             c.r = __builtin_inff();
             if (!(c.op & QR_OPT_BV)) { c.r2 = __builtin_inff(); c.r2x = __builtin_inff(); }   /* no cull: no test of walk_pool's fails */
-            if (c.op & QR_OPF_CULL)
+            if (c.op & QR_OPF_BOX)
+            {
+                /* + box_pad: the slab test's own rounding, 2e-6 of the scene's largest coordinate (qr_walk.hpp) */
+                const BSphere &bb = bs[ch[i].si];
+                c.r2 = bb.lo[0] - box_pad; c.r2x = bb.lo[1] - box_pad; c.cx = bb.lo[2] - box_pad;
+                c.cy = bb.hi[0] + box_pad; c.cz = bb.hi[1] + box_pad; c.r = bb.hi[2] + box_pad;
+            }
+            else if (c.op & QR_OPF_CULL)
             {
                 const BSphere &bsp = (c.op & QR_OPT_BV) ? arr_sphere[i] : bs[ch[i].si];
                 c.cx = bsp.c[0]; c.cy = bsp.c[1]; c.cz = bsp.c[2]; c.r = bsp.r;
@@ -601,7 +624,9 @@ struct Builder
             if (ch[i].op & QR_OPF_CLIP) lf &= ~QR_LISTF_DIV;
             if (ch[i].op & QR_OPT_BV) n_bv++;
         }
-        if (n_emitted >= 96 && n_bv >= 4) { lf |= QR_LISTF_LONG; any_long = true; }
+        /* a long hierarchy: rays part ways on it.  (96 cells until round 3: demo scene 2's ~110-cell lists then put its frames on
+         * the per-lane kernel instance, which renders them at 3 waves per SIMD -- 34.8 against 46.5 Grays/s with this one.) */
+        if (n_emitted >= QR_LONG_CELLS && n_bv >= 4) { lf |= QR_LISTF_LONG; any_long = true; }
         bool world = true;
         for (int i = 0; i < n; i++)
             if (ch[i].emit && ((ch[i].op & QR_OPT_TRNODE) || (ch[i].op & QR_OPF_LOCAL))) world = false;
@@ -943,6 +968,41 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         memcpy(b.at<qr_light>(b.o_lgt), v.lgt, (size_t)n_lgt * sizeof(qr_light));
         memcpy(b.at<uint32_t>(b.o_tex), v.texels, (size_t)n_tex * 4);
 
+        /* box cull cells (QR_OPF_BOX) for images whose lists are all short: no list of such an image can be flagged as a long
+         * hierarchy or get a uniform / shadow grid (each needs a chain of >= QR_LONG_CELLS elements), so only packet walks read its cells.
+         * QR_BOX=0: spheres only (A/B runs, tests). */
+        {
+            /* length of the chain behind every element (chains share tails): follow it to an element already known, unwind */
+            static thread_local std::vector<int32_t> len, stack;
+            len.assign(b.E.size(), 0);
+            int32_t longest = 0;
+            bool ok = true;
+            for (size_t e0 = 0; e0 < b.E.size() && ok; e0++)
+            {
+                if (len[e0] != 0) continue;
+                stack.clear();
+                int e = (int)e0;
+                while (e != QR_NULL && len[e] == 0)
+                {
+                    stack.push_back(e); e = b.E[e].next;
+                    if (stack.size() > b.E.size()) { ok = false; break; }
+                }
+                int32_t l = e != QR_NULL ? len[e] : 0;
+                while (!stack.empty()) { len[stack.back()] = ++l; stack.pop_back(); }
+                if (l > longest) longest = l;
+            }
+            const char *be = getenv("QR_BOX");
+            const bool box_lists = cull_mode >= 3 && !(be && atoi(be) == 0);
+            {
+                double big = 0.0;
+                for (int k = 0; k < 3; k++) big = std::max(big, (double)__builtin_fabsf(frm.org[k]));
+                for (int i = 0; i < n_srf; i++)
+                    if (bs[i].lo[0] <= bs[i].hi[0])
+                        for (int k = 0; k < 3; k++) big = std::max(big, std::max((double)__builtin_fabsf(bs[i].lo[k]), (double)__builtin_fabsf(bs[i].hi[k])));
+                b.box_pad = (float)(2e-6 * big);
+            }
+            b.box_ok = box_lists && ok && longest < QR_LONG_CELLS;
+        }
         tick("setup");
         /* tile lists */
         std::vector<uint32_t> tile_off(T.size());
@@ -1093,6 +1153,8 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         out.stats = b.st;
         out.has_long_lists = b.any_long;
         out.has_grids = b.n_grids != 0;
+        if (b.box_ok && (b.any_long || b.n_grids != 0)) throw Fail{QR_ERR_ARG, "layout: box cull cells in an image with long lists"};
+        b.at<DevHeader>(0)->img_flags = b.any_box ? QR_IMG_BOXES : 0u;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
     tick("finish");
@@ -1152,6 +1214,11 @@ int qr_program_verify(const QrProgram &p, std::string &err)
             if ((c->op & QR_OPF_CACHED) && (c->op & QR_OPF_OWN)) return "bad transform mode";
             if (world && (t == QR_OPT_TRNODE || (c->op & QR_OPF_LOCAL))) return "transform in a list flagged world-space";
             if ((c->op & QR_OPF_CULL) && !(t & (QR_OPT_SOLVER | QR_OPT_BV))) return "cull flag on a cell without solver or volume";
+            if (c->op & QR_OPF_BOX)
+            {
+                if (!(c->op & QR_OPF_CULL) || !(t & QR_OPT_SOLVER) || dda) return "box flag on the wrong kind of cell";
+                if (!(c->r2 <= c->cy) || !(c->r2x <= c->cz) || !(c->cx <= c->r) || !(c->r2 > -1e30f) || !(c->r < 1e30f)) return "box cull cell: bad box";
+            }
             if ((c->op & QR_OPF_SPHBV) && (t != QR_OPT_BV || !(c->op & QR_OPF_CULL) || (c->op & QR_OPF_LOCAL))) return "sphere-volume flag on the wrong kind of cell";
             if ((c->op & QR_OPF_KX) && (c->op & QR_OPF_KY)) return "bad axis k";
             if ((c->op & QR_OPF_IX) && (c->op & QR_OPF_IY)) return "bad axis i";

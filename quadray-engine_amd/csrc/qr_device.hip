@@ -545,8 +545,8 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
         static const char *nm[48] = { "candidates through clip()", "clipper programs run", "clipper cells", "  fast plane cells", "  trnode / trsame cells",
             "  generic plane tests", "  quadric tests", "", "solve: plane cells", "solve: quadric cells", "solve: two-plane cells", "solve in shadow walks", "solve in nearest-hit walks",
             "solve with own / cached transform", "solve with conic fix", "", "cells loaded by packet walks", "  culled by their sphere", "shadow packet walks", "nearest-hit packet walks",
-            "trnode cells", "bounding-volume cells", "", "", "shade() calls", "light rounds", "solves without any accepted hit", "  of them planes", "  of them without a candidate root" };
-        for (int i = 0; i < 29; i++) if (nm[i][0]) fprintf(stderr, "QR_PROF %-36s %llu\n", nm[i], pf[i]);
+            "trnode cells", "bounding-volume cells", "", "", "shade() calls", "light rounds", "solves without any accepted hit", "  of them planes", "  of them without a candidate root", "box cull tests" };
+        for (int i = 0; i < 30; i++) if (nm[i][0]) fprintf(stderr, "QR_PROF %-36s %llu\n", nm[i], pf[i]);
         unsigned long long z[48] = {0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(qr_prof), z, sizeof(z)));
     }

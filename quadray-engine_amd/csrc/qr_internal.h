@@ -23,7 +23,9 @@ int  qr_fail(int status, const std::string &msg);
 
 /* ---- scene compiler (qr_compile.cpp): snapshot -> device image of qr_program.h ---- */
 
-struct BSphere { float c[3]; float r; };    /* conservative world-space bounding sphere, r = +inf: unbounded */
+/* conservative world-space bounds of a surface's visible part: sphere (r = +inf: unbounded) and, where the sphere is bounded,
+ * the axis-aligned box of the same part (lo > hi: none) */
+struct BSphere { float c[3]; float r; float lo[3] = { 1.0f, 1.0f, 1.0f }, hi[3] = { 0.0f, 0.0f, 0.0f }; };
 
 #define QR_SCHED_PER_LANE 0xFFFFFFFEu       /* schedule entry: the footprint straddles tiles, look the list up per pixel */
 

@@ -69,6 +69,10 @@ struct CBvExt
 #define QR_OPF_SIDESHAD (1u << 15)  /*   ... occludes depending on the side hit (look at the props)       */
 #define QR_OPF_CLIP    (1u << 16)   /* surface has custom clippers                                        */
 #define QR_OPF_CONIC   (1u << 17)   /* conic singularity fix applies (cones, hyper-cylinders)             */
+#define QR_OPF_BOX     (1u << 19)   /* cull cell (QR_OPF_CULL, solver cells only): the six cull slots hold an axis-aligned world-space
+                                     * box {lo.xyz, hi.xyz} instead of the sphere {R^2, 1.01 R^2, c.xyz, R}: planes, cylinders, cones --
+                                     * shapes a sphere fits badly.  Only in images whose lists are all short (packet walks serve them);
+                                     * a per-lane walk that meets one (QR_DIV=1) does not cull on it */
 #define QR_OPF_SPHBV   (1u << 18)   /* bounding volume is an untransformed world-space sphere that holds all its members'
                                      * bounds: its cull sphere is that sphere (x 1.0002), the r2x slot holds -1 (0x7F800000
                                      * = +inf otherwise), and the per-lane walk decides most rays from the sphere alone */
@@ -82,6 +86,7 @@ struct CBvExt
 #define QR_LISTF_GRID  8u       /* only in CLight::shadow: the offset is that of a CGrid, the shadow list depends on where the
                                  * surface was hit                                                                        */
 #define QR_LIST_OFF(x) ((x) & ~31u)
+#define QR_LONG_CELLS  192      /* a list needs this many cells (and four bounding volumes) to be flagged QR_LISTF_LONG */
 
 /*
  * Shadow lists of a LARGE surface by hit position (ours; the reference keeps one shadow list per surface and light, so a
@@ -210,7 +215,9 @@ struct DevHeader
     uint32_t off_tiles;         /* tile heads as byte offsets of lists (0 = empty tile)                     */
     uint32_t off_order;         /* whole-frame wave schedule                                                */
     uint32_t n_blocks;
-    uint32_t pad[11];
+    uint32_t img_flags;         /* QR_IMG_*                                                                  */
+    uint32_t pad[10];
 };
+#define QR_IMG_BOXES 1u         /* some cull cell carries a box (QR_OPF_BOX): packet walks prepare the slab test */
 
 #endif /* QR_PROGRAM_H */

@@ -626,7 +626,9 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
  * OO_cyc for the lanes of a wave that share the list program at `head` (wave-uniform, not 0).
  * SHADOW: any-hit walk, ends as soon as every ray is occluded.
  */
-template <bool SHADOW>
+/* BOXC: the walk knows box cull cells (QR_OPF_BOX).  The kernel instance with the per-lane walks is compiled without: images it
+ * serves carry none (qr_compile.cpp), and when it is forced onto one (QR_DIV=1) such a cell is simply not culled */
+template <bool SHADOW, bool BOXC>
 __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &h, bool &occluded
 #ifdef QR_STATS
                                           , unsigned long long *stats
@@ -643,6 +645,19 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
     const float dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
     const float dde = dd * 1e-5f;
     w.tbd = w.tbuf * dd;
+    /* box cull cells (QR_OPF_BOX): slab test with the reciprocal direction; a zero component becomes +-1e-30 (the ray does not
+     * move along that axis: both slab distances come out huge with the sign of the side the origin is on) */
+    float idx = 0.0f, idy = 0.0f, idz = 0.0f, nox = 0.0f, noy = 0.0f, noz = 0.0f;
+    if (BOXC && (c_frm(B)->img_flags & QR_IMG_BOXES))
+    {
+        const float dxs = __builtin_fabsf(r.dir.x) < 1e-30f ? __builtin_copysignf(1e-30f, r.dir.x) : r.dir.x;
+        const float dys = __builtin_fabsf(r.dir.y) < 1e-30f ? __builtin_copysignf(1e-30f, r.dir.y) : r.dir.y;
+        const float dzs = __builtin_fabsf(r.dir.z) < 1e-30f ? __builtin_copysignf(1e-30f, r.dir.z) : r.dir.z;
+        idx = __builtin_amdgcn_rcpf(dxs); idy = __builtin_amdgcn_rcpf(dys); idz = __builtin_amdgcn_rcpf(dzs);
+        /* slab distance (bound - org) / dir as one fused operation, bound * id - org * id: its error, an ulp of |org * id|, is
+         * 6e-8 |org| in space -- the boxes are padded by 2e-6 of the scene's largest coordinate on top of their own margin */
+        nox = -(r.org.x * idx); noy = -(r.org.y * idy); noz = -(r.org.z * idz);
+    }
     u32 pos = __builtin_amdgcn_readfirstlane(head);
     QR_PROF_HIT(SHADOW ? 18 : 19);      /* packet walks */
 #ifdef QR_STATS
@@ -673,14 +688,31 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
             c = *(const QR_CONST u32x8 *)(B + pos);
             QR_PROF_HIT(16);            /* cells loaded by packet walks */
-            if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV)) != QR_OPF_CULL) break;
-            const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
-            const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
-            const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
-            const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
-            const float q = oc2 - R2;
-            const lm_t miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
-                            | LM(__builtin_fmaf(-R, dlen, b) > w.tbd);
+            if ((c.s0 & (QR_OPF_CULL | QR_OPT_BV | (BOXC ? 0u : QR_OPF_BOX))) != QR_OPF_CULL) break;
+            lm_t miss;
+            if (BOXC && (c.s0 & QR_OPF_BOX))
+            {
+                /* axis-aligned box {lo, hi} of the surface's visible part (inflated at upload, far above the rounding here):
+                 * the ray misses it when it leaves one slab before it has entered all three, when the box lies behind the
+                 * origin, or when it lies beyond the depth bound */
+                const float ax = __builtin_fmaf(u2f(c.s2), idx, nox), bx = __builtin_fmaf(u2f(c.s5), idx, nox);
+                const float ay = __builtin_fmaf(u2f(c.s3), idy, noy), by = __builtin_fmaf(u2f(c.s6), idy, noy);
+                const float az = __builtin_fmaf(u2f(c.s4), idz, noz), bz = __builtin_fmaf(u2f(c.s7), idz, noz);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+                const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+                miss = LM(tn > tf) | LM(tf < 0.0f) | LM(tn > w.tbuf * 1.00001f);
+                QR_PROF_HIT(29);
+            }
+            else
+            {
+                const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
+                const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
+                const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
+                const float oc2 = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+                const float q = oc2 - R2;
+                miss = (LM(oc2 > R2x) & LM(__builtin_fmaf(oc2, dde, b * __builtin_fabsf(b)) < dd * q))
+                     | LM(__builtin_fmaf(-R, dlen, b) > w.tbd);
+            }
             const lm_t need = LM(w.resume <= pos) & ~(miss & LM(c.s1 != r.osrf));
 #ifdef QR_STATS
             st_iter++; st_lanes += __popcll(LM(w.resume <= pos));
@@ -861,12 +893,13 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
                 if (op == 0) next = 0;
                 else if (op & QR_OPT_SOLVER)
                 {
-                    if (!(op & QR_OPF_CULL) || !div_culled(a0, a1, r, dd, dde, dlen, w.tbd)) { p_op = op; p_srf = srf_off; }
+                    /* (a box cull cell, QR_OPF_BOX, holds no sphere: the per-lane walks do not cull on it) */
+                    if ((op & (QR_OPF_CULL | QR_OPF_BOX)) != QR_OPF_CULL || !div_culled(a0, a1, r, dd, dde, dlen, w.tbd)) { p_op = op; p_srf = srf_off; }
                     else if ((b0.x & QR_OPT_SOLVER) != 0)
                     {
                         /* second cell of the load */
                         next = pos + 64;
-                        if (!(b0.x & QR_OPF_CULL) || !div_culled(b0, b1, r, dd, dde, dlen, w.tbd)) { p_op = b0.x; p_srf = b0.y; }
+                        if ((b0.x & (QR_OPF_CULL | QR_OPF_BOX)) != QR_OPF_CULL || !div_culled(b0, b1, r, dd, dde, dlen, w.tbd)) { p_op = b0.x; p_srf = b0.y; }
                     }
                 }
                 else if (op & QR_OPT_BV)
@@ -1135,7 +1168,8 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                     u32 bv_end = a0.z;
                     asm volatile("" : "+v"(bv_end));
                     float b2, m, rhs;
-                    const bool culled = pool_cull(srf_off, a1, is_bv ? u2f(b1.w) : u2f(a0.z), u2f(a0.w), is_bv, cr, dd, dde, dlen, w.tbd, b2, m, rhs);
+                    const bool culled = (op & QR_OPF_BOX) == 0
+                                     && pool_cull(srf_off, a1, is_bv ? u2f(b1.w) : u2f(a0.z), u2f(a0.w), is_bv, cr, dd, dde, dlen, w.tbd, b2, m, rhs);
                     if (is_bv)
                     {
                         next = pos + 64;
@@ -1155,7 +1189,7 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                     {
                         /* second cell of the load */
                         next = pos + 64;
-                        if (!pool_cull(b0.y, b1, u2f(b0.z), u2f(b0.w), false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
+                        if ((b0.x & QR_OPF_BOX) != 0 || !pool_cull(b0.y, b1, u2f(b0.z), u2f(b0.w), false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
                         { p_op = b0.x; p_srf = b0.y; p_pos = pos + 32; }
                     }
                 }
@@ -1559,7 +1593,7 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         pending &= ~mine;
         if (lane_of(mine))
         {
-            walk_list<SHADOW>(B, head & ~31u, r, h, occluded
+            walk_list<SHADOW, !DIVK>(B, head & ~31u, r, h, occluded
 #ifdef QR_STATS
                               , stats
 #endif
