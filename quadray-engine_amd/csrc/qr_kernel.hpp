@@ -328,15 +328,29 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 
     /* recursion frames: levels 0..LDSL-1 in LDS ([level][quarter][lane]: a quarter of all lanes is contiguous,
      * 16-byte accesses at a 16-byte lane stride), deeper levels in scratch */
-    constexpr int LDSL = PT ? 1 : (DIVK ? QR_LDS_LEVELS_DIVK : QR_LDS_LEVELS);
+    /* Ray tracer: a frame's first two quarters (colour so far, factors: all a node with ONE child ever reads back) live in LDS
+     * for the four shallowest levels and in scratch below; the other two (the second child's origin, direction and local hit:
+     * only written by a node with BOTH children) in scratch.  8 KB of LDS per wave as before, but of the frames demo scene 2
+     * pushes at 3840x2160 with 4x FSAA -- 18 M with one child, 9 M with two, a third of them deeper than level 1 -- most never
+     * touch scratch now.  Path tracer (six quarters: its bounce): one whole level in LDS. */
+    constexpr int LDSL = PT ? 1 : 0;
+    constexpr int NLDS = PT ? 0 : QR_LDS_NARROW_LEVELS;
     constexpr int FQ = PT ? 6 : 4;              /* quarters per frame: the path tracer also keeps its bounce (q4, q5) */
-    __shared__ f32x4 lds_frames[LDSL][FQ][64];
-    f32x4 deep[QR_MAX_DEPTH - LDSL][FQ];
+    __shared__ f32x4 lds_frames[LDSL > 0 ? LDSL : 1][FQ][PT ? 64 : 1];
+    __shared__ f32x4 lds_narrow[NLDS > 0 ? NLDS : 1][2][PT ? 1 : 64];
+    f32x4 deep[PT ? QR_MAX_DEPTH - LDSL : 1][FQ];
+    f32x4 deep_narrow[PT ? 1 : QR_MAX_DEPTH - NLDS][2];
+    f32x4 deep_wide[PT ? 1 : QR_MAX_DEPTH][2];
     auto frame_put = [&](int level, int quarter, f32x4 v) {
-        if (level < LDSL) lds_frames[level][quarter][lane] = v; else deep[level - LDSL][quarter] = v;
+        if constexpr (PT) { if (level < LDSL) lds_frames[level][quarter][lane] = v; else deep[level - LDSL][quarter] = v; }
+        else if (quarter >= 2) deep_wide[level][quarter - 2] = v;
+        else if (level < NLDS) lds_narrow[level][quarter][lane] = v;
+        else deep_narrow[level - NLDS][quarter] = v;
     };
     auto frame_get = [&](int level, int quarter) -> f32x4 {
-        return level < LDSL ? lds_frames[level][quarter][lane] : deep[level - LDSL][quarter];
+        if constexpr (PT) return level < LDSL ? lds_frames[level][quarter][lane] : deep[level - LDSL][quarter];
+        else if (quarter >= 2) return deep_wide[level][quarter - 2];
+        else return level < NLDS ? lds_narrow[level][quarter][lane] : deep_narrow[level - NLDS][quarter];
     };
     Outer ou;
     ou.sp = 0;
@@ -414,6 +428,18 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
                         frame_put(sp, 5, f32x4{o.pdir.x, o.pdir.y, o.pdir.z, 0.0f});
                     }
                 }
+#ifdef QR_PROF
+                {
+                    /* frames pushed, by level (lanes): wide = both children, narrow = one */
+                    const bool wide = o.want_tr && can_spawn && (o.want_rf || has_pt), narrow = can_spawn && !wide && (o.want_tr || o.want_rf);
+                    for (int lv = 0; lv < 8; lv++)
+                    {
+                        const unsigned long long nw = __popcll(__ballot(wide && (sp < 7 ? sp : 7) == lv)), nn = __popcll(__ballot(narrow && (sp < 7 ? sp : 7) == lv));
+                        if (nw) QR_PROF_ADD(32 + lv, nw);
+                        if (nn) QR_PROF_ADD(40 + lv, nn);
+                    }
+                }
+#endif
                 if (o.want_tr && can_spawn)
                 {
                     frame_put(sp, 0, f32x4{o.col.x, o.col.y, o.col.z, __int_as_float(meta | 1)});

@@ -23,9 +23,9 @@ struct Frame
     float rdir[3]; float hit1;          /* q2: the reflection child's direction */
     float loc[3]; float hit2;           /* q3: the local hit (the child's ploc) */
 };
-#define QR_LDS_LEVELS 2
-#ifndef QR_LDS_LEVELS_DIVK
-#define QR_LDS_LEVELS_DIVK 2    /* + 2.5 KB for walk_pool / walk_dda: 10.5 KB per wave, 12 waves per CU (3 per SIMD) fit */
+#ifndef QR_LDS_NARROW_LEVELS
+#define QR_LDS_NARROW_LEVELS 4  /* levels whose first two quarters live in LDS (2 KB per level and wave); the kernel instance with the
+                                 * per-lane walks adds 2.5 KB for walk_pool / walk_dda: 10.5 KB per wave, 12 waves per CU fit */
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
