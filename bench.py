@@ -94,6 +94,11 @@ def committed_counters(workload):
         if c is not None:
             c = dict(c)
             c["measured_in_this_run"] = False
+            # quoted only beside a run of the build they were taken from (qr_version() carries the source fingerprint)
+            from qr_loader import load_package
+            this_lib = load_package().lib().qr_version().decode()
+            if c.get("lib") != this_lib:
+                c = dict(stale=True, lib=c.get("lib"), this_lib=this_lib, source=c.get("source"), measured_in_this_run=False)
         return c
     except Exception:
         return None
@@ -402,14 +407,20 @@ def main():
         work = algorithmic_work(snap)
         flops, flops_src = None, None
         if work is not None and work["rays"] == rays_per_frame:
-            flops, flops_src = work["flops"], "oracle count of the whole frame, tests/golden/work.json"
+            flops, flops_src = work["flops"], work.get("source", "oracle count of the whole frame") + ", tests/golden/work.json"
         elif cpu is not None and cpu.get("band"):
             flops = int(cpu["band"]["flops"] / max(1, cpu["band"]["rays"]) * rays_per_frame)
             flops_src = "oracle count on the cpu_baseline band, scaled by rays"
         counters = committed_counters(args.workload)
+        if counters is not None and counters.get("stale"):
+            roofline_stale, counters = counters, None
+        else:
+            roofline_stale = None
         roofline = dict(bound="valu", achieved=None, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
                         traffic=(counters or {}).get("hbm_bytes_per_launch"),
                         kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms)
+        if roofline_stale is not None:
+            roofline["counters"] = roofline_stale
         if flops is not None:
             tf = flops / (avg_ms * 1e-3) / 1e12
             roofline.update(achieved=tf, frac=tf / VALU_PEAK_TFLOPS, flops_per_launch=flops, flops_source=flops_src)
@@ -439,13 +450,16 @@ def main():
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": ("synthetic scene (quadray-engine_amd/synth.py)" if snap.startswith("synth:") else
+                     f"the reference's own scene: snapshot of the engine's scene graph (tests/golden/{snap}.qrs.gz), no dataset involved"),
             "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
                        "frames_per_step": N, "steps_in_flight": D, "rays_per_frame": rays_per_frame,
                        "rays": rc.as_dict(),
                        "parallelism": f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
                        "frame_check": frame_check, "assembled_frame_matches": ok},
+            "lib": qr.lib().qr_version().decode(),
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

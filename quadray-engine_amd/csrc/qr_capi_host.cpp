@@ -20,7 +20,11 @@ int qr_fail(int status, const std::string &msg)
 
 extern "C" const char *qr_last_error(void) { return g_qr_error.c_str(); }
 
-extern "C" const char *qr_version(void) { return "qrhip 0.1 (gfx950)"; }
+#ifndef QR_SRC_HASH
+#define QR_SRC_HASH "unknown"
+#endif
+/* "... src <12 hex digits>": fingerprint of the sources this library was built from (csrc/Makefile SRC_HASH) */
+extern "C" const char *qr_version(void) { return "qrhip 0.3 (gfx950) src " QR_SRC_HASH; }
 
 extern "C" int qr_flatten(const void *s_inf, const qr_abi_desc *abi, void **blob, uint64_t *size)
 {

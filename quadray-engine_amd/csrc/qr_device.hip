@@ -547,6 +547,7 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
             "solve with own / cached transform", "solve with conic fix", "", "cells loaded by packet walks", "  culled by their sphere", "shadow packet walks", "nearest-hit packet walks",
             "trnode cells", "bounding-volume cells", "", "", "shade() calls", "light rounds", "solves without any accepted hit", "  of them planes", "  of them without a candidate root", "box cull tests" };
         for (int i = 0; i < 30; i++) if (nm[i][0]) fprintf(stderr, "QR_PROF %-36s %llu\n", nm[i], pf[i]);
+        fprintf(stderr, "QR_PROF algorithmic fp32 operations executed (SURVEY 8(d) weights, per lane) %llu\n", pf[47]);
         fprintf(stderr, "QR_PROF frames pushed by level 0..7+ (lanes), both children:");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", pf[32 + i]);
         fprintf(stderr, "\nQR_PROF frames pushed by level 0..7+ (lanes), one child:    ");

@@ -81,9 +81,15 @@ typedef uint32_t u32;
 __device__ unsigned long long qr_prof[48];
 #define QR_PROF_HIT(i) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], 1ull); } while (0)
 #define QR_PROF_ADD(i, n) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], (unsigned long long)(n)); } while (0)
+/* algorithmic fp32 operations the kernel executes, with the weights of SURVEY.md 8(d) as oracle/qr_oracle.c applies them (FL()):
+ * n operations for every lane that is active here / for every lane of `mask` */
+#define QR_FLOPS(n) QR_PROF_ADD(47, (unsigned long long)(n) * (unsigned long long)__popcll(__ballot(true)))
+#define QR_FLOPS_M(n, cnt) QR_PROF_ADD(47, (unsigned long long)(n) * (unsigned long long)(cnt))
 #else
 #define QR_PROF_HIT(i) do { } while (0)
 #define QR_PROF_ADD(i, n) do { } while (0)
+#define QR_FLOPS(n) do { } while (0)
+#define QR_FLOPS_M(n, cnt) do { } while (0)
 #endif
 
 /* what a launch needs besides the scene image: kernel arguments */
@@ -362,6 +368,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     const int depth = lp.depth;
 
     if (COUNT && inside) cnt.primary++;
+    QR_FLOPS_M(16, __popcll(__ballot(inside)));             /* primary ray */
 
     bool eager_done = false;
     if constexpr (PT)
@@ -612,6 +619,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             ret = {ar, ag, ab};
         }
     }
+    QR_FLOPS_M(6 + 2 * fsaa, __popcll(__ballot(inside)));
     /* XX_end 5161-5343: clamp, FSAA reduce, gamma, pack */
     float cr = clamp1(ret.x), cg = clamp1(ret.y), cb = clamp1(ret.z);
     if (fsaa >= 1)

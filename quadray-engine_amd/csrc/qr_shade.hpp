@@ -158,6 +158,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         nrm = ln;
         if (has_trm != 0)
         {
+            QR_FLOPS(24);
             /* MT_nrm 2184-2263: transposed trnode matrix */
             const DSurf *__restrict__ tr = (const DSurf *)(G + s->trn);
             const int ttrm = (int)DF_TRM(tr->flags);
@@ -274,6 +275,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
     }
 
     QR_PROF_HIT(24);                    /* shade() calls */
+    if (pt_stage != 2 && pt_stage != 3) QR_FLOPS_M(16 + 4 + 6, __popcll(__ballot(act)));            /* normal, texture look-up, ambient */
     /* lights, 2758-3156: wave-wide loop, per-lane light-list entries */
     while (any_lane(le != 0))
     {
@@ -286,6 +288,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         bool lm = false;
         if (has)
         {
+            QR_FLOPS(8);
             float x1, x2, x3, x0;
             x1 = lg->pos[0] - hit.x; L.x = x1; x1 = x1 * nrm.x;
             x2 = lg->pos[1] - hit.y; L.y = x2; x2 = x2 * nrm.y;
@@ -344,8 +347,10 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
             x4 = x4 + x5; x4 = x4 + x6;
             const float r2 = x4;
             x0 = dot;
+            QR_FLOPS(10);
             if (props & QR_PROP_DIFFUSE)
             {
+                QR_FLOPS(17);
                 x6 = x4;
                 x5 = rsq(x4);
                 x4 = x5 * x6;
@@ -379,6 +384,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
                 x1 = x1 + x2; x1 = x1 + x3;
                 if (clt(0.0f, x1))
                 {
+                    QR_FLOPS(32);
                     x4 = r2;
                     x5 = rsq(x6); x1 = x1 * x5;
                     x5 = rsq(x4); x1 = x1 * x5;
@@ -461,6 +467,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         /* transparency 3185-3552 */
         if (!(props & QR_PROP_OPAQUE))
         {
+            QR_FLOPS(65);
             const bool do_rfi = (props & QR_PROP_REFRACT) || (props & QR_PROP_FRESNEL);
             bool tir = false;
             V3 nd = r.dir;
@@ -554,6 +561,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
         if ((props & QR_PROP_REFLECT) ||
             (!(props & QR_PROP_OPAQUE) && (props & QR_PROP_FRESNEL)))
         {
+            QR_FLOPS(24);
             x1 = r.dir.x; x4 = nrm.x; x7 = x1 * x1; x0 = x7;
             x2 = r.dir.y; x5 = nrm.y; x7 = x2 * x2; x0 = x0 + x7;
             x3 = r.dir.z; x6 = nrm.z; x7 = x3 * x3; x0 = x0 + x7;
@@ -568,6 +576,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
 
             if ((props & QR_PROP_FRESNEL) && (props & QR_PROP_OPAQUE))
             {
+                QR_FLOPS(16);
                 if (props & QR_PROP_METAL)
                 {
                     x6 = mt->c_rcp;

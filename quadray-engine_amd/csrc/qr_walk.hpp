@@ -58,6 +58,11 @@ template <> struct MK<true>
     static __device__ __forceinline__ T none() { return false; }
 };
 
+#ifdef QR_PROF
+__device__ __forceinline__ unsigned long long qr_lanes(lm_t m) { return (unsigned long long)__popcll(m); }
+__device__ __forceinline__ unsigned long long qr_lanes(bool m) { return (unsigned long long)__popcll(__ballot(m)); }
+#endif
+
 /* what clip() needs to know about the candidate's surface space */
 template <bool DIV>
 struct ClipIn
@@ -153,6 +158,7 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
 {
     typedef MK<DIV> K;
     QR_PROF_HIT(0);                     /* candidates through clip() */
+    QR_FLOPS_M(15, qr_lanes(m));
     /* the opcode is re-read through an opaque copy: otherwise everything that only depends on it (the whole
      * axis decode of the conic fix, every flag as a 64-bit mask) is hoisted in front of the candidate loop and
      * paid by every cell */
@@ -193,6 +199,7 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
         const typename K::T hm = K::of(clt(x0, s.t_eps)) & ci.dmask;
         if (K::any(hm))
         {
+            QR_FLOPS_M(16, qr_lanes(hm));
             if (K::lane(hm))
             {
                 const u32 sm = QR_SMASK;
@@ -263,6 +270,9 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
             const u32 cop = cc.s0;
             if (cop == 0) break;
             QR_PROF_HIT(2);             /* clipper cells */
+            if (!(cop & (QR_CLT_ENTER | QR_CLT_LEAVE)))
+                QR_FLOPS_M(((cop & QR_CLT_PLANE) ? 3 : ((cop & (QR_CLT_QUAD | QR_CLT_QUADJ)) ? 3 + 18 : 3))
+                           + (((cop & (QR_CLT_TRNODE | QR_CLF_OWN)) && !(cop & QR_CLT_TRSAME)) ? ((cop & QR_CLF_FULLM) ? 15 : 3) : 0), qr_lanes(m));
             if (cop & QR_CLF_FASTPL)
             {
                 QR_PROF_HIT(3);
@@ -446,6 +456,8 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
         mask_t cm0 = K::none(), cm1 = K::none();
         int   ncand = 0;
 
+        /* diff 3, own transform of diff and ray 2 x (3 or 15), solver 1 / 31 + 10 / 21 */
+        QR_FLOPS(3 + ((op & QR_OPF_OWN) ? ((op & QR_OPF_FULLM) ? 30 : 6) : 0) + ((op & QR_OPT_PLANE) ? 1 : ((op & QR_OPT_QUADRIC) ? 41 : 21)));
         QR_PROF_HIT((op & QR_OPT_PLANE) ? 8 : ((op & QR_OPT_QUADRIC) ? 9 : 10));
         QR_PROF_HIT(SHADOW ? 11 : 12);
         if (op & (QR_OPF_OWN | QR_OPF_CACHED)) QR_PROF_HIT(13);
@@ -751,6 +763,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             if (op & QR_OPT_TRNODE)
             {
                 QR_PROF_HIT(20);
+                QR_FLOPS_M(3 + ((op & QR_OPF_FULLM) ? 30 : 6), __popcll(on));
                 /* array element with a transform: diff and ray in its space, cached for the surfaces behind it */
                 if (lane_of(on))
                 {
@@ -765,6 +778,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
             {
                 /* AR_ptr 3955-4054; the volume travels with the cell (CBvExt) */
                 QR_PROF_HIT(21);
+                QR_FLOPS_M(3 + 25, __popcll(on & ~far));
                 next = pos + 64;
                 const u32x8 x = *(const QR_CONST u32x8 *)(B + pos + 32);
                 if (lane_of(on & ~far))
@@ -917,6 +931,7 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
                     if (far) next = a0.z;
                     else
                     {
+                        QR_FLOPS(3 + 25);
                         V3 df, ry;
                         cell_space(B, op, srf_off, u2f(b0.x), u2f(b0.y), u2f(b0.z), r, w, df, ry);
                         if (!bv_hit(ry, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w))) next = a0.z;
@@ -1166,7 +1181,9 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                      * the exact test below and a lane that fails that test continues at a garbage offset (seen in the ISA,
                      * caught by the QR_GUARD build) */
                     u32 bv_end = a0.z;
+#ifndef QR_NO_BVEND_COPY        /* -DQR_NO_BVEND_COPY: the build without the copy, for the ISA comparison in DESIGN.md */
                     asm volatile("" : "+v"(bv_end));
+#endif
                     float b2, m, rhs;
                     const bool culled = (op & QR_OPF_BOX) == 0
                                      && pool_cull(srf_off, a1, is_bv ? u2f(b1.w) : u2f(a0.z), u2f(a0.w), is_bv, cr, dd, dde, dlen, w.tbd, b2, m, rhs);
@@ -1177,6 +1194,7 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
                         if (enter && !((op & QR_OPF_SPHBV) != 0 && b2 - m >= rhs))
                         {
                             /* AR_ptr itself: not a plain sphere, or the ray passes within rounding of its surface */
+                            QR_FLOPS(3 + 25);
                             V3 df;
                             df.x = cr.org.x - u2f(b0.x); df.y = cr.org.y - u2f(b0.y); df.z = cr.org.z - u2f(b0.z);
                             enter = bv_hit(cr.dir, df, u2f(b1.x), u2f(b1.y), u2f(b1.z), u2f(b1.w));

@@ -237,3 +237,18 @@ def test_gpu_random_synth_scenes_match_oracle(qr, oracle, seed, n, box):
     _, _, o_counts = oracle.render(blob, threads=16, deferred=True)
     _, c = scn.render_count()
     assert c.as_dict() == {k: o_counts[k] for k in c.as_dict()}
+
+
+@pytest.mark.gpu
+def test_gpu_guarded_build_finds_no_bad_cell_offset():
+    """The QR_STATS + QR_GUARD build of the kernels (every cell offset of the per-lane walks -- walk_div, walk_pool with its
+    hand-over, walk_dda -- checked before it is loaded) renders synthetic crowds of 300 / 2 000 / 10 000 objects and a swarm
+    fixture: no bad offset, frames equal to the oracle's.  (Round 2's memory-access fault was such an offset)"""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "quadray-engine_amd", "libqrhip_guard.so")
+    if not os.path.exists(lib):
+        pytest.skip("libqrhip_guard.so not built (make -C quadray-engine_amd/csrc guard)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_guard_check.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("frame_ok 1") == 4 and "QR_GUARD" not in out.stdout, out.stdout

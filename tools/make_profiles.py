@@ -49,6 +49,7 @@ def overlap(d):
 bench = open(os.path.join(G, f"{tag}_bench_n1.json")).read().strip().splitlines()[-1]
 open(os.path.join(P, f"{rnd}_bench_n1.json"), "w").write(bench + "\n")
 b = json.loads(bench)
+lib = b.get("lib")            # qr_version() of the build every pass of this run used: bench.py quotes counters only beside the same build
 
 out = [f"# {rnd} profile of the BASELINE metric workload demo1_1080p, default build, git {git}\n",
        "# tools/gpu_profile_round.sh on one MI355X: rocprofv3 --kernel-trace --stats (serial launches, --inflight 1), separate --pmc passes;\n",
@@ -84,7 +85,7 @@ for w in ("demo1_1080p", "demo1_1080p_d0", "demo2_1080p_gf_d3", "demo2_2160p_aa4
              insts_vmem_rd=cc.get("SQ_INSTS_VMEM_RD"), insts_vmem_wr=cc.get("SQ_INSTS_VMEM_WR"),
              waves=cc.get("SQ_WAVES"), wave_cycles=cc.get("SQ_WAVE_CYCLES"),
              lane_utilisation=cc["SQ_THREAD_CYCLES_VALU"] / (64 * cc["SQ_INSTS_VALU"]) if cc.get("SQ_THREAD_CYCLES_VALU") else None,
-             source=f"profiles/{rnd}_counters_all_workloads.txt (rocprofv3 --pmc passes of tools/gpu_profile_round.sh)", git=git)
+             source=f"profiles/{rnd}_counters_all_workloads.txt (rocprofv3 --pmc passes of tools/gpu_profile_round.sh)", git=git, lib=lib)
     if "FETCH_SIZE" in cc and "WRITE_SIZE" in cc:
         # MI355X_MICROARCH.md: FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> doubled; both in KiB
         e.update(fetch_size_kib=cc["FETCH_SIZE"], write_size_kib=cc["WRITE_SIZE"],
@@ -93,7 +94,7 @@ for w in ("demo1_1080p", "demo1_1080p_d0", "demo2_1080p_gf_d3", "demo2_2160p_aa4
 json.dump(cj, open(os.path.join(P, "counters.json"), "w"), indent=1, sort_keys=True)
 lines = [f"# {rnd} per-launch hardware counters of qr_render_kernel<false,4>, all workloads, git {git} (tools/gpu_profile_round.sh)\n"]
 for w, e in cj.items():
-    lines.append(w + ": " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in e.items() if k not in ("source", "git")) + "\n")
+    lines.append(w + ": " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in e.items() if k not in ("source", "git", "lib")) + "\n")
 open(os.path.join(P, f"{rnd}_counters_all_workloads.txt"), "w").write("".join(lines))
 
 import shutil
