@@ -540,20 +540,21 @@ extern "C" int qr_render_count(qr_device_scene *s, void *frame_dev, void *stream
     counts->primary = h[0]; counts->shadow = h[1]; counts->reflect = h[2]; counts->refract = h[3];
 #ifdef QR_PROF
     {
-        unsigned long long pf[48];
+        unsigned long long pf[64];
         HIP_TRY(hipMemcpyFromSymbol(pf, HIP_SYMBOL(qr_prof), sizeof(pf)));
         static const char *nm[48] = { "candidates through clip()", "clipper programs run", "clipper cells", "  fast plane cells", "  trnode / trsame cells",
             "  generic plane tests", "  quadric tests", "", "solve: plane cells", "solve: quadric cells", "solve: two-plane cells", "solve in shadow walks", "solve in nearest-hit walks",
             "solve with own / cached transform", "solve with conic fix", "", "cells loaded by packet walks", "  culled by their sphere", "shadow packet walks", "nearest-hit packet walks",
             "trnode cells", "bounding-volume cells", "", "", "shade() calls", "light rounds", "solves without any accepted hit", "  of them planes", "  of them without a candidate root", "box cull tests" };
         for (int i = 0; i < 30; i++) if (nm[i][0]) fprintf(stderr, "QR_PROF %-36s %llu\n", nm[i], pf[i]);
-        fprintf(stderr, "QR_PROF algorithmic fp32 operations executed (SURVEY 8(d) weights, per lane) %llu\n", pf[47]);
+        fprintf(stderr, "QR_PROF algorithmic fp32 operations executed (SURVEY 8(d) weights, per lane) %llu\n", pf[48]);
+        fprintf(stderr, "QR_PROF fp32 operations of the implementation's own culls (sphere / box tests, walk set-up) %llu\n", pf[49]);
         fprintf(stderr, "QR_PROF frames pushed by level 0..7+ (lanes), both children:");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", pf[32 + i]);
         fprintf(stderr, "\nQR_PROF frames pushed by level 0..7+ (lanes), one child:    ");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", pf[40 + i]);
         fprintf(stderr, "\n");
-        unsigned long long z[48] = {0};
+        unsigned long long z[64] = {0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(qr_prof), z, sizeof(z)));
     }
 #endif

@@ -78,18 +78,22 @@ typedef uint32_t u32;
 /* -DQR_PROF builds: wave-level event counters in a device global, printed by qr_render_count (where does a frame's instruction
  * budget go: tools/gpu_prof.py) */
 #ifdef QR_PROF
-__device__ unsigned long long qr_prof[48];
+__device__ unsigned long long qr_prof[64];
 #define QR_PROF_HIT(i) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], 1ull); } while (0)
 #define QR_PROF_ADD(i, n) do { if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) atomicAdd(&qr_prof[i], (unsigned long long)(n)); } while (0)
 /* algorithmic fp32 operations the kernel executes, with the weights of SURVEY.md 8(d) as oracle/qr_oracle.c applies them (FL()):
  * n operations for every lane that is active here / for every lane of `mask` */
-#define QR_FLOPS(n) QR_PROF_ADD(47, (unsigned long long)(n) * (unsigned long long)__popcll(__ballot(true)))
-#define QR_FLOPS_M(n, cnt) QR_PROF_ADD(47, (unsigned long long)(n) * (unsigned long long)(cnt))
+#define QR_FLOPS(n) QR_PROF_ADD(48, (unsigned long long)(n) * (unsigned long long)__popcll(__ballot(true)))
+#define QR_FLOPS_M(n, cnt) QR_PROF_ADD(48, (unsigned long long)(n) * (unsigned long long)(cnt))
+/* beside them, the arithmetic of this implementation's own culls (no step of SURVEY 8(d): never part of a roofline numerator):
+ * walk set-up 9 (+ 6 with box cells), sphere test 20, box slab test 22 */
+#define QR_CULL_FLOPS(n) QR_PROF_ADD(49, (unsigned long long)(n) * (unsigned long long)__popcll(__ballot(true)))
 #else
 #define QR_PROF_HIT(i) do { } while (0)
 #define QR_PROF_ADD(i, n) do { } while (0)
 #define QR_FLOPS(n) do { } while (0)
 #define QR_FLOPS_M(n, cnt) do { } while (0)
+#define QR_CULL_FLOPS(n) do { } while (0)
 #endif
 
 /* what a launch needs besides the scene image: kernel arguments */

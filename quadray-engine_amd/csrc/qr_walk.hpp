@@ -672,6 +672,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
     }
     u32 pos = __builtin_amdgcn_readfirstlane(head);
     QR_PROF_HIT(SHADOW ? 18 : 19);      /* packet walks */
+    QR_CULL_FLOPS((BOXC && (c_frm(B)->img_flags & QR_IMG_BOXES)) ? 15 : 9);
 #ifdef QR_STATS
     unsigned long long st_iter = 0, st_lanes = 0, st_skip = 0;
 #endif
@@ -714,9 +715,11 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
                 const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
                 miss = LM(tn > tf) | LM(tf < 0.0f) | LM(tn > w.tbuf * 1.00001f);
                 QR_PROF_HIT(29);
+                QR_CULL_FLOPS(22);
             }
             else
             {
+                QR_CULL_FLOPS(20);
                 const float R = u2f(c.s7), R2 = u2f(c.s2), R2x = u2f(c.s3);
                 const float ocx = u2f(c.s4) - r.org.x, ocy = u2f(c.s5) - r.org.y, ocz = u2f(c.s6) - r.org.z;
                 const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
@@ -838,6 +841,7 @@ __device__ __forceinline__ void ld_surf_lane(BaseP B, u32 off, SurfS &s)
 /* per-lane form of the cell cull of walk_list: c0 = {op, srf, R^2, 1.01 R^2}, c1 = {cx, cy, cz, R} */
 __device__ __forceinline__ bool div_culled(const u32x4 &c0, const u32x4 &c1, const Ray &r, float dd, float dde, float dlen, float tbd)
 {
+    QR_CULL_FLOPS(20);
     const float R = u2f(c1.w), R2 = u2f(c0.z), R2x = u2f(c0.w);
     const float ocx = u2f(c1.x) - r.org.x, ocy = u2f(c1.y) - r.org.y, ocz = u2f(c1.z) - r.org.z;
     const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));
@@ -1041,6 +1045,7 @@ __device__ __forceinline__ int lanes_below(lm_t m)
 __device__ __forceinline__ bool pool_cull(u32 srf, const u32x4 &c1, float r2, float out2, bool line, const Ray &r,
                                           float dd, float dde, float dlen, float tbd, float &b2, float &m, float &rhs)
 {
+    QR_CULL_FLOPS(22);
     const float R = u2f(c1.w);
     const float ocx = u2f(c1.x) - r.org.x, ocy = u2f(c1.y) - r.org.y, ocz = u2f(c1.z) - r.org.z;
     const float b = __builtin_fmaf(ocz, r.dir.z, __builtin_fmaf(ocy, r.dir.y, ocx * r.dir.x));

@@ -4,7 +4,8 @@
 Counted by the CPU oracle (oracle/qr_oracle.c, FL() weights) on the committed snapshots, in both
 shading modes: "eager" = the reference's semantics (every depth-test winner is shaded), "deferred"
 = only the final hit of a list walk is shaded (what the HIP backend executes; same pixels).
-Deterministic per (snapshot, depth); written to tests/golden/work.json.
+Deterministic per (snapshot, depth); written to tests/golden/work.json.  Entries named "kernel" (and the whole entry of a
+synthetic workload) are the kernel's own count of the same steps, put there by tools/gpu_work.py on a GPU box: kept as they are.
 
     python tests/golden/make_work.py
 """
@@ -15,10 +16,13 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import qr_oracle
 
 SNAPS = ["c2b_demo01_1080p", "c2_demo01_1080p_d0", "c3_demo02_1080p_gf_d3", "c4_demo02_2160p_aa4_gf", "swarm_demo01_240_1080p"]
-out = {}
+try:
+    out = json.load(open(os.path.join(HERE, "work.json")))
+except Exception:
+    out = {}
 for name in SNAPS:
     blob = gzip.decompress(open(os.path.join(HERE, name + ".qrs.gz"), "rb").read())
-    rec = {}
+    rec = out.get(name, {})
     for mode, d in (("eager", False), ("deferred", True)):
         _, _, c = qr_oracle.render(blob, threads=8, deferred=d)
         rays = c["primary"] + c["shadow"] + c["reflect"] + c["refract"]
