@@ -72,6 +72,24 @@ typedef struct qr_abi_desc
 int qr_render0(const void *s_inf, const qr_abi_desc *abi);
 
 /*
+ * Several devices and caller-owned frames (both optional; they apply to qr_render0 and qr_render_host alike).
+ *
+ * QR_DEVICES=0,1,... (environment): the frame is cut into bands of tile rows, one band per entry of the list; every entry
+ * renders its band on its device and copies it into the host frame itself -- no exchange between devices, the bands meet in
+ * the caller's frame as the rows of the engine's worker threads do (tracer.cpp:1144-1145, engine.cpp:3465-3478).  The same
+ * ordinal may be listed several times (separate buffers and streams on that device).  Without it: QR_DEVICE (default 0).
+ *
+ * qr_frame_register: page-locks [frame, frame + bytes) so that rendered rows are written into it by the devices' copy
+ * engines directly (no staging frame, no host copy; strides and index / thnum row ownership are honoured).  It is the
+ * caller's promise that the range stays mapped until qr_frame_unregister; qr_render0 itself never retains a pointer it
+ * was handed (the engine may free its frame between two calls, engine.cpp:3317-3323).  The binding calls it where the
+ * reference allocates the frame and the inverse where it frees it (rt_Scene's constructor / destructor, engine.cpp:2814-
+ * 2850 / 3790-3800: INTEGRATION.md).  Frames with a negative stride are served through the staging path.
+ */
+int qr_frame_register(void *frame, uint64_t bytes);
+int qr_frame_unregister(void *frame);
+
+/*
  * Same walk as qr_render0 but, instead of rendering, serialises the flattened
  * scene (include/qr_scene.h) to `path`.  Needs no GPU.  This is how snapshots
  * travel from a machine that has the reference engine to one that does not.
@@ -221,7 +239,8 @@ int qr_render_count(qr_device_scene *scn, void *frame_dev, void *stream, qr_ray_
 
 /*
  * Convenience: render to a HOST frame buffer (stride `row_pixels`, may be
- * negative like the reference's x_row), synchronous.
+ * negative like the reference's x_row), synchronous.  With several entries in QR_DEVICES a whole-frame call renders one
+ * band per entry (the scene image is copied to the other devices on the first such call, peer to peer).
  */
 int qr_render_host(qr_device_scene *scn, uint32_t *frame_host, int row_pixels);
 

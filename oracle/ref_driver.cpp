@@ -61,7 +61,7 @@
 #include <algorithm>
 
 /* set by the shim-linked binary: where the next shim call writes its snapshot */
-extern "C" { const char *qr_shim_snapshot_path = NULL; int qr_shim_calls = 0; int qr_shim_status = 0; }
+extern "C" { const char *qr_shim_snapshot_path = NULL; int qr_shim_calls = 0; int qr_shim_status = 0; double qr_shim_ms = 0.0; }
 
 static double now_ms()
 {
@@ -236,6 +236,8 @@ static void usage()
  * The engine keeps these members private; this TU is compiled with -fno-access-control (oracle/Makefile).
  */
 extern "C" int qr_capture_index(int kind, const void *record) __attribute__((weak));   /* libqrhip: qr_ref_shim only */
+extern "C" int qr_frame_register(void *frame, unsigned long long bytes) __attribute__((weak));
+extern "C" int qr_frame_unregister(void *frame) __attribute__((weak));
 static int capture_index(int kind, const void *r) { return qr_capture_index ? qr_capture_index(kind, r) : -1; }
 
 static void put_f(FILE *f, const char *key, const rt_real *v, int n)
@@ -427,7 +429,7 @@ int main(int argc, char **argv)
     int pt_frames = 0;
     const char *scene_name = NULL, *out_path = NULL, *snap_path = NULL, *opts_mode = NULL, *tree_path = NULL, *opts_off = NULL;
     int pt_warm = 0;
-    int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0;
+    int w = 640, h = 480, fsaa = 0, depth = -1, bench = 0, gamma = 0, fresnel = 0, camera = 0, gpu = 0, pin_frame = 0;
     int n_simd = 0, k_size = 0, s_type = 0;
     long time_ms = 0, animate_ms = 0, swarm_seed = 0;
     int swarm_n = 0, swarm_mix = 0;
@@ -451,6 +453,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--snapshot") && i + 1 < argc) snap_path = argv[++i];
         else if (!strcmp(argv[i], "--bench") && i + 1 < argc) bench = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gpu")) gpu = 1;
+        else if (!strcmp(argv[i], "--pin-frame")) pin_frame = 1;      /* what the binding does where the engine allocates its frame: qr_frame_register */
         else if (!strcmp(argv[i], "--animate") && i + 1 < argc) animate_ms = atol(argv[++i]);
         else if (!strcmp(argv[i], "--camera") && i + 1 < argc) camera = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--pt") && i + 1 < argc) pt_frames = atoi(argv[++i]);
@@ -552,6 +555,13 @@ int main(int argc, char **argv)
             }
             pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
             memset(frame, 0, (size_t)row * h * 4);
+            if (pin_frame)
+            {
+                if (qr_frame_register == NULL || row < w) { fprintf(stderr, "--pin-frame: not available\n"); return 4; }
+                const int prc = qr_frame_register(frame, (unsigned long long)row * h * 4);
+                printf("pin_frame rc %d\n", prc);
+                if (prc != 0) return 4;
+            }
             qr_shim_snapshot_path = NULL;
             qr_shim_calls = 0;
             sc->render(time_ms);
@@ -584,19 +594,23 @@ int main(int argc, char **argv)
         {
             pfm->set_simd(simd_init(1, 8, 1));
             pfm->set_fsaa(fsaa == 4 ? RT_FSAA_4X : fsaa == 2 ? RT_FSAA_2X : RT_FSAA_NO);
-            std::vector<double> ms;
+            std::vector<double> ms, in_call;
             long t_last = t_next;
             for (int i = 0; i < bench; i++)
             {
+                qr_shim_ms = 0.0;
                 double t0 = now_ms();
                 sc->render(t_next);
                 ms.push_back(now_ms() - t0);
+                in_call.push_back(qr_shim_ms);
                 t_last = t_next;
                 t_next += animate_ms;
             }
-            std::sort(ms.begin(), ms.end());
-            printf("gpu_bench frames %d animate_ms %ld min_ms %.3f median_ms %.3f (engine update + flatten + compile + upload + kernel + copy back)\n",
-                   bench, animate_ms, ms[0], ms[ms.size() / 2]);
+            std::sort(ms.begin(), ms.end()); std::sort(in_call.begin(), in_call.end());
+            /* median_ms: the whole rt_Scene::render (the engine's own update of the scene + the backend call);
+             * call_median_ms: inside qr_render0 only (flatten + compile + upload + kernel + copy back) */
+            printf("gpu_bench frames %d animate_ms %ld min_ms %.3f median_ms %.3f call_median_ms %.3f engine_side_median_ms %.3f (engine update | flatten + compile + upload + kernel + copy back)\n",
+                   bench, animate_ms, ms[0], ms[ms.size() / 2], in_call[in_call.size() / 2], ms[ms.size() / 2] - in_call[in_call.size() / 2]);
             if (animate_ms != 0)
             {
                 /* the last animated frame once more on both backends: the frames must be equal */

@@ -17,7 +17,8 @@
 #include "system.h"     /* rt_Exception */
 #include "qrhip.h"
 
-extern "C" { extern const char *qr_shim_snapshot_path; extern int qr_shim_calls; extern int qr_shim_status; }
+#include <time.h>
+extern "C" { extern const char *qr_shim_snapshot_path; extern int qr_shim_calls; extern int qr_shim_status; extern double qr_shim_ms; }
 
 namespace simd_128v8
 {
@@ -25,9 +26,13 @@ namespace simd_128v8
 rt_void render0(rt_SIMD_INFOX *s_inf)
 {
     qr_abi_desc abi = { sizeof(qr_abi_desc), Q, RT_POINTER, RT_ADDRESS, RT_ELEMENT, RT_ENDIAN, {0, 0} };
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
     int rc = qr_shim_snapshot_path != RT_NULL
            ? qr_capture_snapshot(s_inf, &abi, qr_shim_snapshot_path)
            : qr_render0(s_inf, &abi);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    qr_shim_ms += (double)(b.tv_sec - a.tv_sec) * 1e3 + (double)(b.tv_nsec - a.tv_nsec) * 1e-6;      /* time inside the backend call */
     qr_shim_calls++;
     qr_shim_status = rc;
     if (rc != QR_OK)

@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "qr_scene_upload", "qr_scene_upload_ex", "qr_program_stats", "qr_snapshot_build_lists_c", "qr_scene_destroy", "qr_scene_get_info", "qr_scene_set_depth", "qr_scene_set_pt",
     "qr_scene_set_rows", "qr_scene_set_tile_rows", "qr_render_async", "qr_render_multi_async", "qr_render_ids_async",
     "qr_render_count", "qr_render_host", "qr_render_timed",
+    "qr_frame_register", "qr_frame_unregister",
     "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name", "qr_capture_index",
     # include/qr_hierarchy.h
     "qr_hierarchy_update", "qr_hierarchy_animate", "qr_hierarchy_apply", "qr_anim_spin", "qr_anim_swing",
@@ -100,6 +101,8 @@ def lib():
     L.qr_render_multi_async.argtypes = [ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ci), ctypes.POINTER(ci), vp]
     L.qr_render_count.argtypes = [vp, vp, vp, ctypes.POINTER(RayCounts)]
     L.qr_render_host.argtypes = [vp, vp, ci]
+    L.qr_frame_register.argtypes = [vp, ctypes.c_uint64]
+    L.qr_frame_unregister.argtypes = [vp]
     L.qr_render_timed.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.qr_hierarchy_update.argtypes = [vp, ci, ctypes.c_uint32, vp]
     L.qr_hierarchy_animate.argtypes = [vp, ci, ctypes.c_int64, vp, vp, vp, ci]
@@ -118,6 +121,15 @@ def read_snapshot(path):
     with open(path, "rb") as f:
         raw = f.read()
     return gzip.decompress(raw) if path.endswith(".gz") else raw
+
+
+def frame_register(arr):
+    """qr_frame_register on a numpy array the caller keeps alive until frame_unregister(arr)."""
+    _check(lib().qr_frame_register(arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+
+def frame_unregister(arr):
+    _check(lib().qr_frame_unregister(arr.ctypes.data_as(ctypes.c_void_p)))
 
 
 def frame_hash(frame):
@@ -306,10 +318,12 @@ class Scene:
                                      iters, ctypes.byref(avg), ctypes.byref(mn)))
         return avg.value, mn.value
 
-    def render_host(self):
+    def render_host(self, out=None, row_pixels=None):
+        """qr_render_host into a new (or the given) host frame; `row_pixels`: its stride in pixels."""
         import numpy as np
-        out = np.zeros((self.height, self.width), dtype=np.uint32)
-        _check(lib().qr_render_host(self._h, out.ctypes.data_as(ctypes.c_void_p), self.width))
+        if out is None:
+            out = np.zeros((self.height, self.width), dtype=np.uint32)
+        _check(lib().qr_render_host(self._h, out.ctypes.data_as(ctypes.c_void_p), self.width if row_pixels is None else row_pixels))
         return out
 
 

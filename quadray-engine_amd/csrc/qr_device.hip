@@ -622,6 +622,7 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
 /* per-thread device frame + pinned staging buffer, kept between calls: the drop-in path renders a frame
  * per call, and hipMalloc/hipFree plus a pageable 8 MB copy cost more than the kernel itself */
 #define QR_COPY_CHUNKS 4
+#define QR_MAX_DEVICES 8
 
 /* copy into the caller's frame with non-temporal stores: the frame is written once and not read by us, so
  * read-for-ownership traffic and cache pollution of a plain memcpy are avoided (8 MB per frame) */
@@ -648,18 +649,215 @@ static void copy_streaming(void *dst, const void *src, size_t n)
 #endif
 }
 
+/*
+ * QR_DEVICES=0,1,...: the frame of a host-frame call (qr_render0, qr_render_host) is cut into blocks of rows, one run of
+ * blocks per entry of the list; every entry renders its rows on its device and copies them into the host frame itself
+ * (tracer.cpp:1144-1145 / engine.cpp:3465-3478: the engine's threads own rows index, index + thnum, ... of one frame and write
+ * them in place -- here a device owns a band).  The same ordinal may be listed more than once (separate buffers and
+ * streams on that device: how a one-GPU box tests the path).  Without QR_DEVICES: the one device of QR_DEVICE (default 0).
+ */
+static std::vector<int> device_list()
+{
+    std::vector<int> v;
+    if (const char *e = getenv("QR_DEVICES"))
+    {
+        const char *p = e;
+        while (*p)
+        {
+            while (*p == ',' || *p == ' ') p++;
+            if (!*p) break;
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            v.push_back((int)d);
+            p = end;
+        }
+    }
+    if (v.empty()) { int d = 0; if (const char *e = getenv("QR_DEVICE")) d = atoi(e); v.push_back(d); }
+    if (v.size() > QR_MAX_DEVICES) v.resize(QR_MAX_DEVICES);
+    return v;
+}
+
+/*
+ * Caller frames registered for direct copies (qr_frame_register): rendered rows go from device memory straight into
+ * such a frame by DMA -- no page-locked staging frame, no host copy.  The registration is the CALLER's statement that the
+ * range stays mapped until qr_frame_unregister: the library never pins a pointer it merely saw in a call (the engine may
+ * free its frame between two calls, engine.cpp:3317-3323 / 2814-2850).
+ */
+struct PinnedRange { uintptr_t base; size_t bytes; };
+static std::vector<PinnedRange> g_pins;
+static std::mutex g_pins_lock;
+
+extern "C" int qr_frame_register(void *frame, uint64_t bytes)
+{
+    if (frame == nullptr || bytes == 0) return qr_fail(QR_ERR_ARG, "null frame");
+    const int rc = pick_device(device_list()[0]);
+    if (rc != QR_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_pins_lock);
+    for (const PinnedRange &r : g_pins)
+        if (r.base == (uintptr_t)frame) return r.bytes == bytes ? QR_OK : qr_fail(QR_ERR_ARG, "frame is registered with another size");
+    HIP_TRY(hipHostRegister(frame, (size_t)bytes, hipHostRegisterPortable));
+    g_pins.push_back({ (uintptr_t)frame, (size_t)bytes });
+    return QR_OK;
+}
+
+extern "C" int qr_frame_unregister(void *frame)
+{
+    std::lock_guard<std::mutex> lk(g_pins_lock);
+    for (size_t i = 0; i < g_pins.size(); i++)
+        if (g_pins[i].base == (uintptr_t)frame)
+        {
+            g_pins.erase(g_pins.begin() + (ptrdiff_t)i);
+            HIP_TRY(hipHostUnregister(frame));
+            return QR_OK;
+        }
+    return qr_fail(QR_ERR_ARG, "frame was not registered");
+}
+
+static bool frame_is_pinned(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pins_lock);
+    for (const PinnedRange &r : g_pins)
+        if ((uintptr_t)p >= r.base && (uintptr_t)p + bytes <= r.base + r.bytes) return true;
+    return false;
+}
+
+/* rows [y0, y1) of a device frame (compact, w pixels a row) that belong to index / thnum, into a registered host frame */
+static hipError_t copy_rows_direct(uint32_t *frame_host, int row_pixels, const uint32_t *d_frame, int w, int y0, int y1,
+                                   int index, int thnum, hipStream_t st)
+{
+    if (thnum <= 1)
+    {
+        if (y1 <= y0) return hipSuccess;
+        if (row_pixels == w) return hipMemcpyAsync(frame_host + (size_t)y0 * w, d_frame + (size_t)y0 * w, (size_t)(y1 - y0) * w * 4, hipMemcpyDeviceToHost, st);
+        return hipMemcpy2DAsync(frame_host + (size_t)y0 * row_pixels, (size_t)row_pixels * 4, d_frame + (size_t)y0 * w, (size_t)w * 4,
+                                (size_t)w * 4, (size_t)(y1 - y0), hipMemcpyDeviceToHost, st);
+    }
+    const int first = y0 + ((index - y0 % thnum) % thnum + thnum) % thnum;
+    if (first >= y1) return hipSuccess;
+    const int rows = (y1 - first + thnum - 1) / thnum;
+    return hipMemcpy2DAsync(frame_host + (size_t)first * row_pixels, (size_t)thnum * row_pixels * 4, d_frame + (size_t)first * w, (size_t)thnum * w * 4,
+                            (size_t)w * 4, (size_t)rows, hipMemcpyDeviceToHost, st);
+}
+
+/* rows [y0, y1) of a compact staging frame that belong to index / thnum, into the caller's frame (any stride, also negative:
+ * bottom-up frames, engine.cpp:2814-2850) */
+static void copy_rows_host(uint32_t *frame_host, int row_pixels, const uint32_t *h_frame, int w, int y0, int y1, int index, int thnum)
+{
+    if (thnum <= 1 && row_pixels == w) { copy_streaming(frame_host + (size_t)y0 * w, h_frame + (size_t)y0 * w, (size_t)(y1 - y0) * w * 4); return; }
+    for (int y = y0; y < y1; y++)
+    {
+        if (thnum > 1 && (y % thnum) != index) continue;
+        memcpy(frame_host + (ptrdiff_t)y * row_pixels, h_frame + (size_t)y * w, (size_t)w * 4);
+    }
+}
+
+/* bytes of the caller's frame a call may touch (positive stride), 0: not addressable as one range */
+static size_t frame_span(int w, int h, int row_pixels)
+{
+    if (row_pixels < w || h <= 0) return 0;
+    return ((size_t)(h - 1) * (size_t)row_pixels + (size_t)w) * 4;
+}
+
+/* ---- qr_render_host: uploaded scene -> host frame ---- */
+
+/* what one entry of QR_DEVICES holds for an uploaded scene (several entries only) */
+struct HostReplica
+{
+    int device = -1;
+    void *d_blob = nullptr; bool own_blob = false;
+    unsigned long long *d_counters = nullptr;
+    void *d_frame = nullptr; size_t d_cap = 0;
+    uint32_t *d_order = nullptr; int32_t n_order = 0; int y0 = 0, y1 = 0;
+    hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+};
+
 struct HostPathCache
 {
     int device = -1;
     void *d_frame = nullptr; size_t d_cap = 0;
     uint32_t *h_frame = nullptr; size_t h_cap = 0;
     hipEvent_t ev[QR_COPY_CHUNKS] = {};
+    /* QR_DEVICES with several entries: replicas of the scene this thread rendered last */
+    const qr_device_scene *rep_scene = nullptr; uint64_t rep_bytes = 0; const void *rep_blob = nullptr;
+    std::vector<int> rep_devices;
+    std::vector<HostReplica> rep;
     ~HostPathCache()
     {
         /* the HIP runtime may already be shut down when thread-locals are destroyed at exit: leak */
     }
 };
 static thread_local HostPathCache g_hpc;
+
+static void replicas_release(HostPathCache &c)
+{
+    for (HostReplica &r : c.rep)
+    {
+        if (r.device < 0 || hipSetDevice(r.device) != hipSuccess) continue;
+        (void)hipDeviceSynchronize();
+        if (r.own_blob) (void)hipFree(r.d_blob);
+        (void)hipFree(r.d_counters); (void)hipFree(r.d_frame); (void)hipFree(r.d_order);
+        if (r.st) (void)hipStreamDestroy(r.st);
+        if (r.ev) (void)hipEventDestroy(r.ev);
+    }
+    c.rep.clear(); c.rep_scene = nullptr; c.rep_blob = nullptr; c.rep_bytes = 0; c.rep_devices.clear();
+}
+
+/* the kernel instance an uploaded scene renders with, for an explicit schedule / image / counter block */
+static hipError_t launch_instance(const qr_device_scene *s, const LaunchP &lp, uint32_t *frame_dev, unsigned long long *counters, hipStream_t st)
+{
+    if (lp.n_blocks <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((lp.n_blocks + (QR_BLOCK / 64) - 1) / (QR_BLOCK / 64)), 1, 1);
+    if (s->divk) hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), grid, dim3(QR_BLOCK), 0, st, lp, frame_dev, (int32_t *)nullptr, counters);
+    else         hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), grid, dim3(QR_BLOCK), 0, st, lp, frame_dev, (int32_t *)nullptr, counters);
+    return hipGetLastError();
+}
+
+/* (re)build the replicas of `s` for the device list: image copies (peer copy from the scene's device), the schedule entries
+ * of every band, a frame buffer, a stream */
+static int replicas_prepare(HostPathCache &c, qr_device_scene *s, const std::vector<int> &devs)
+{
+    if (c.rep_scene == s && c.rep_blob == s->d_blob && c.rep_bytes == s->blob_bytes && c.rep_devices == devs) return QR_OK;
+    replicas_release(c);
+    const int n = (int)devs.size(), H = s->fr.frm_h, W = s->fr.frm_w;
+    const int fh = s->fr.fsaa == 0 ? 8 : 4;
+    c.rep.resize((size_t)n);
+    for (int j = 0; j < n; j++)
+    {
+        HostReplica &r = c.rep[(size_t)j];
+        int rc = pick_device(devs[(size_t)j]);
+        if (rc != QR_OK) { replicas_release(c); return rc; }
+        r.device = devs[(size_t)j];
+        /* bands of whole 8-row groups */
+        const int groups = (H + 7) / 8;
+        r.y0 = (int)((long long)groups * j / n) * 8; r.y1 = j == n - 1 ? H : (int)((long long)groups * (j + 1) / n) * 8;
+        if (r.y1 > H) r.y1 = H;
+        std::vector<uint32_t> keep;
+        for (size_t i = 0; i + 1 < s->h_order.size(); i += 2)
+        {
+            const int fy = (int)((s->h_order[i] >> 14) & 0x3FFFu) * fh;
+            if (fy + fh > r.y0 && fy < r.y1) { keep.push_back(s->h_order[i]); keep.push_back(s->h_order[i + 1]); }
+        }
+        r.n_order = (int32_t)(keep.size() / 2);
+        hipError_t e = hipSuccess;
+        if (r.device == s->device) r.d_blob = s->d_blob;
+        else
+        {
+            e = hipMalloc(&r.d_blob, s->blob_bytes);
+            if (e == hipSuccess) { r.own_blob = true; e = hipMemcpyPeer(r.d_blob, r.device, s->d_blob, s->device, s->blob_bytes); }
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&r.d_counters, 64 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(r.d_counters, 0, 64 * sizeof(unsigned long long));
+        if (e == hipSuccess) { r.d_cap = (size_t)W * H * 4; e = hipMalloc(&r.d_frame, r.d_cap); }
+        if (e == hipSuccess && r.n_order > 0) e = hipMalloc((void **)&r.d_order, keep.size() * 4);
+        if (e == hipSuccess && r.n_order > 0) e = hipMemcpy(r.d_order, keep.data(), keep.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.ev, hipEventDisableTiming);
+        if (e != hipSuccess) { replicas_release(c); return qr_fail(QR_ERR_DEVICE, std::string("QR_DEVICES replica: ") + hipGetErrorString(e)); }
+    }
+    c.rep_scene = s; c.rep_blob = s->d_blob; c.rep_bytes = s->blob_bytes; c.rep_devices = devs;
+    return QR_OK;
+}
 
 extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_pixels)
 {
@@ -669,6 +867,49 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
     { const int rc = pt_rows_ok(s); if (rc != QR_OK) return rc; }
     HIP_TRY(hipSetDevice(s->device));
     HostPathCache &c = g_hpc;
+    const bool whole = s->lp.row_begin == 0 && s->lp.row_end == h && s->lp.group_first == 0 && s->lp.group_stride == 1 && s->lp.thnum <= 1;
+    const size_t span = frame_span(w, h, row_pixels);
+    const bool pinned = span != 0 && frame_is_pinned(frame_host, span);
+    if (c.h_cap < bytes && !pinned)
+    {
+        if (c.h_frame) (void)hipHostFree(c.h_frame);
+        c.h_frame = nullptr; c.h_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&c.h_frame, bytes, hipHostMallocPortable));
+        c.h_cap = bytes;
+    }
+
+    /* ---- several devices: one band of rows each ---- */
+    const std::vector<int> devs = getenv("QR_DEVICES") ? device_list() : std::vector<int>();
+    if (devs.size() > 1 && whole && !s->pt_on)
+    {
+        int rc = replicas_prepare(c, s, devs);
+        if (rc != QR_OK) return rc;
+        hipError_t e = hipSuccess;
+        for (HostReplica &r : c.rep)
+        {
+            if (e != hipSuccess) break;
+            e = hipSetDevice(r.device);
+            if (e != hipSuccess) break;
+            LaunchP lp = s->lp;
+            lp.B = (const char *)r.d_blob; lp.order = r.d_order; lp.n_blocks = r.n_order;
+            lp.row_begin = r.y0; lp.row_end = r.y1; lp.stats = r.d_counters + 4;
+            e = launch_instance(s, lp, (uint32_t *)r.d_frame, r.d_counters, r.st);
+            if (e != hipSuccess) break;
+            if (pinned) e = copy_rows_direct(frame_host, row_pixels, (const uint32_t *)r.d_frame, w, r.y0, r.y1, 0, 1, r.st);
+            else if (r.y1 > r.y0) e = hipMemcpyAsync(c.h_frame + (size_t)r.y0 * w, (const uint32_t *)r.d_frame + (size_t)r.y0 * w, (size_t)(r.y1 - r.y0) * w * 4, hipMemcpyDeviceToHost, r.st);
+            if (e == hipSuccess) e = hipEventRecord(r.ev, r.st);
+        }
+        for (HostReplica &r : c.rep)
+        {
+            if (e != hipSuccess) break;
+            e = hipEventSynchronize(r.ev);
+            if (e == hipSuccess && !pinned) copy_rows_host(frame_host, row_pixels, c.h_frame, w, r.y0, r.y1, 0, 1);
+        }
+        (void)hipSetDevice(s->device);
+        if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render (QR_DEVICES): ") + hipGetErrorString(e));
+        return QR_OK;
+    }
+
     if (c.device != s->device || c.d_cap < bytes)
     {
         if (c.d_frame) { (void)hipSetDevice(c.device); (void)hipFree(c.d_frame); (void)hipSetDevice(s->device); }
@@ -676,15 +917,19 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
         HIP_TRY(hipMalloc(&c.d_frame, bytes));
         c.d_cap = bytes;
     }
-    if (c.h_cap < bytes)
-    {
-        if (c.h_frame) (void)hipHostFree(c.h_frame);
-        c.h_frame = nullptr; c.h_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&c.h_frame, bytes, hipHostMallocDefault));
-        c.h_cap = bytes;
-    }
-    const bool whole = s->lp.row_begin == 0 && s->lp.row_end == h && s->lp.group_first == 0 && s->lp.group_stride == 1 && s->lp.thnum <= 1;
     hipError_t e = launch<false>(s, c.d_frame, nullptr, nullptr);
+    if (e == hipSuccess && pinned)
+    {
+        /* registered frame: the rows this call owns by DMA, straight into it */
+        if (s->lp.group_stride == 1)
+            e = copy_rows_direct(frame_host, row_pixels, (const uint32_t *)c.d_frame, w, s->lp.row_begin, s->lp.row_end, s->lp.index, s->lp.thnum, nullptr);
+        else
+            for (int g = s->lp.group_first; g * 8 < h && e == hipSuccess; g += s->lp.group_stride)
+                e = copy_rows_direct(frame_host, row_pixels, (const uint32_t *)c.d_frame, w, g * 8, g * 8 + 8 < h ? g * 8 + 8 : h, s->lp.index, s->lp.thnum, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) return qr_fail(QR_ERR_DEVICE, std::string("render: ") + hipGetErrorString(e));
+        return QR_OK;
+    }
     if (e == hipSuccess && whole && row_pixels == w && h >= 64)
     {
         /* compact whole frame: the copy back runs in QR_COPY_CHUNKS row bands, the DMA of band k+1 under
@@ -734,12 +979,14 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
  * The reference entry point.  One call = flatten + compile + upload + launch + copy back; nothing of the
  * caller's memory is retained (the engine releases its pools every frame, engine.cpp:3317-3323).
  *
- * What IS kept, per calling thread, is our own: a device arena for the scene image and the frame (no hipMalloc /
- * hipFree per call), page-locked staging buffers, two streams and the vectors of the host passes.  The frame is
- * rendered in QR_DROPIN_BLOCKS horizontal blocks (the schedule is grouped by block): block k is copied back over
- * PCIe on the copy stream while block k + 1 renders, and the host moves finished blocks into the caller's frame
- * (non-temporal stores) while the next copy is in flight.  When the flattened scene is byte-identical to the one
- * this thread uploaded last (a paused animation), validation, compilation and upload are skipped.
+ * What IS kept, per calling thread, is our own: per entry of QR_DEVICES (one entry without it) a device arena for the
+ * scene image and the frame (no hipMalloc / hipFree per call) and streams; page-locked staging buffers and the vectors
+ * of the host passes.  The frame is rendered in horizontal blocks (the schedule is grouped by block), QR_DROPIN_BLOCKS of
+ * them on one device, a run of blocks per device on several: block k is copied back over PCIe on its device's copy
+ * stream while block k + 1 renders, and the host moves finished blocks into the caller's frame (non-temporal stores)
+ * while the next copy is in flight -- or, when the caller has registered its frame (qr_frame_register), the copy engines
+ * write the blocks straight into it.  When the flattened scene is byte-identical to the one this thread uploaded last (a
+ * paused animation), validation, compilation and upload are skipped.
  */
 #ifndef QR_DROPIN_BLOCKS
 #define QR_DROPIN_BLOCKS 4
@@ -748,27 +995,36 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
 #endif
 #endif
 
-struct DropIn
+/* what one entry of the device list holds on its device */
+struct DropSlot
 {
     int device = -1;
     void *d_blob = nullptr; size_t d_cap = 0;
-    uint8_t *h_stage = nullptr; size_t h_cap = 0;
     void *d_frame = nullptr; size_t df_cap = 0;
-    uint32_t *h_frame = nullptr; size_t hf_cap = 0;
     unsigned long long *d_counters = nullptr; size_t n_counters = 0;
     hipStream_t sk = nullptr, sc = nullptr;
     hipStream_t sx[QR_DROPIN_BLOCKS] = {};     /* one launch stream per row block (sx[0] == sk): a block's tail overlaps the next block's bulk */
     hipEvent_t ev_up = nullptr;                 /* uploads of this call are on the device */
     hipEvent_t ev_k[QR_DROPIN_BLOCKS] = {}, ev_c[QR_DROPIN_BLOCKS] = {};
+    bool resident = false;              /* the thread's current program is the image in d_blob */
+    uint32_t *d_pt = nullptr; size_t pt_cap = 0;   /* path-tracer mode: device copies of the engine's seed plane and three colour planes */
+};
+
+struct DropIn
+{
+    DropSlot slot[QR_MAX_DEVICES];
+    int n_slots = 0;
+    uint8_t *h_stage = nullptr; size_t h_cap = 0;      /* page-locked, portable: every device uploads from it */
+    uint32_t *h_frame = nullptr; size_t hf_cap = 0;
     std::vector<uint8_t> blob, last_blob;
     QrProgram prog;
-    bool resident = false;              /* prog is the image in d_blob */
-    uint32_t *d_pt = nullptr; size_t pt_cap = 0;   /* path-tracer mode: device copies of the engine's seed plane and three colour planes */
+    bool compiled = false;              /* prog is the program of last_blob ... */
+    int compiled_blocks = 0;            /* ... with its schedule grouped for this many row blocks */
 };
 static thread_local DropIn g_drop;
 
-/* everything a DropIn holds on its device; the caller has made that device current */
-static void dropin_release(DropIn &c)
+/* everything a slot holds on its device; the caller has made that device current */
+static void slot_release(DropSlot &c)
 {
     (void)hipDeviceSynchronize();
     for (int k = 1; k < QR_DROPIN_BLOCKS; k++) if (c.sx[k]) (void)hipStreamDestroy(c.sx[k]);
@@ -777,20 +1033,11 @@ static void dropin_release(DropIn &c)
     if (c.ev_up) (void)hipEventDestroy(c.ev_up);
     for (int k = 0; k < QR_DROPIN_BLOCKS; k++) { if (c.ev_k[k]) (void)hipEventDestroy(c.ev_k[k]); if (c.ev_c[k]) (void)hipEventDestroy(c.ev_c[k]); }
     (void)hipFree(c.d_blob); (void)hipFree(c.d_frame); (void)hipFree(c.d_counters); (void)hipFree(c.d_pt);
-    if (c.h_stage) (void)hipHostFree(c.h_stage);
-    if (c.h_frame) (void)hipHostFree(c.h_frame);
-    c.sk = c.sc = nullptr; c.ev_up = nullptr;
-    for (int k = 0; k < QR_DROPIN_BLOCKS; k++) { c.sx[k] = nullptr; c.ev_k[k] = nullptr; c.ev_c[k] = nullptr; }
-    c.d_blob = nullptr; c.d_cap = 0; c.h_stage = nullptr; c.h_cap = 0;
-    c.d_frame = nullptr; c.df_cap = 0; c.h_frame = nullptr; c.hf_cap = 0;
-    c.d_counters = nullptr; c.n_counters = 0;
-    c.d_pt = nullptr; c.pt_cap = 0;
-    c.resident = false;
-    c.device = -1;
+    c = DropSlot();
 }
 
-/* streams, events: created together; on any failure nothing is kept (c.device stays -1, the next call starts over) */
-static int dropin_create(DropIn &c)
+/* streams, events: created together; on any failure nothing is kept (the slot's device stays -1, the next call starts over) */
+static int slot_create(DropSlot &c)
 {
     HIP_TRY(hipStreamCreateWithFlags(&c.sk, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c.sc, hipStreamNonBlocking));
@@ -805,17 +1052,17 @@ static int dropin_create(DropIn &c)
     return QR_OK;
 }
 
-static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_bytes, size_t n_sched)
+static int slot_prepare(DropSlot &c, int dev, size_t image_bytes, size_t frame_bytes, size_t n_sched)
 {
     if (c.device != dev)
     {
         /* first call of this thread, or another device: what the previous device held is released there first;
          * c.device is only set once every stream and event exists, so a failure leaves no half-built state behind */
-        if (c.device >= 0) { if (hipSetDevice(c.device) == hipSuccess) dropin_release(c); c.device = -1; }
+        if (c.device >= 0) { if (hipSetDevice(c.device) == hipSuccess) slot_release(c); c.device = -1; }
         int rc = pick_device(dev);
         if (rc != QR_OK) return rc;
-        rc = dropin_create(c);
-        if (rc != QR_OK) { dropin_release(c); return rc; }
+        rc = slot_create(c);
+        if (rc != QR_OK) { slot_release(c); return rc; }
         c.device = dev;
     }
     else HIP_TRY(hipSetDevice(dev));
@@ -844,14 +1091,6 @@ static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_b
         HIP_TRY(hipMalloc(&c.d_blob, cap));
         c.d_cap = cap;
     }
-    if (c.h_cap < image_bytes)
-    {
-        if (c.h_stage) (void)hipHostFree(c.h_stage);
-        c.h_stage = nullptr; c.h_cap = 0;
-        const size_t cap = image_bytes + image_bytes / 2 + (1u << 20);
-        HIP_TRY(hipHostMalloc((void **)&c.h_stage, cap, hipHostMallocDefault));
-        c.h_cap = cap;
-    }
     if (c.df_cap < frame_bytes)
     {
         if (c.d_frame) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c.d_frame); }
@@ -859,11 +1098,26 @@ static int dropin_prepare(DropIn &c, int dev, size_t image_bytes, size_t frame_b
         HIP_TRY(hipMalloc(&c.d_frame, frame_bytes));
         c.df_cap = frame_bytes;
     }
+    return QR_OK;
+}
+
+/* the thread's page-locked staging buffers (some device is current) */
+static int dropin_host_buffers(DropIn &c, size_t image_bytes, size_t frame_bytes)
+{
+    if (c.h_cap < image_bytes)
+    {
+        if (c.h_stage) (void)hipHostFree(c.h_stage);
+        c.h_stage = nullptr; c.h_cap = 0;
+        for (int j = 0; j < QR_MAX_DEVICES; j++) c.slot[j].resident = false;       /* the image every upload reads is gone */
+        const size_t cap = image_bytes + image_bytes / 2 + (1u << 20);
+        HIP_TRY(hipHostMalloc((void **)&c.h_stage, cap, hipHostMallocPortable));
+        c.h_cap = cap;
+    }
     if (c.hf_cap < frame_bytes)
     {
         if (c.h_frame) (void)hipHostFree(c.h_frame);
         c.h_frame = nullptr; c.hf_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&c.h_frame, frame_bytes, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c.h_frame, frame_bytes, hipHostMallocPortable));
         c.hf_cap = frame_bytes;
     }
     return QR_OK;
@@ -882,7 +1136,7 @@ struct DropInPt
     int first = 0, step = 1, rows = 0;
 };
 
-static int dropin_pt_begin(DropIn &c, const void *s_inf, const qr_abi_desc *abi, const qr_frame &fr, DropInPt &io, PtParams &pt)
+static int dropin_pt_begin(DropSlot &c, const void *s_inf, const qr_abi_desc *abi, const qr_frame &fr, DropInPt &io, PtParams &pt)
 {
     uint8_t *inf = (uint8_t *)(uintptr_t)s_inf;         /* the counter below is the one field of s_inf render0 writes */
     const size_t ps = abi->pointer_bits / 8, Q = abi->quads, P = abi->pointer_bits / 32;
@@ -926,7 +1180,7 @@ static int dropin_pt_begin(DropIn &c, const void *s_inf, const qr_abi_desc *abi,
     return QR_OK;
 }
 
-static hipError_t dropin_pt_end(DropIn &c, const DropInPt &io)
+static hipError_t dropin_pt_end(DropSlot &c, const DropInPt &io)
 {
     hipError_t e = hipSuccess;
     for (int k = 0; k < 4 && io.rows > 0 && e == hipSuccess; k++)
@@ -958,18 +1212,24 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     uint32_t *frame_host = (uint32_t *)(uintptr_t)p_frame;
     const int row_pixels = (int)row;
 
-    int dev = 0;
-    if (const char *env = getenv("QR_DEVICE")) dev = atoi(env);
+    /* the devices of this call, and with them the number of row blocks of the schedule: QR_DROPIN_BLOCKS on one device,
+     * a run of blocks (at least one) for each of several.  A path-traced frame stays on the first device: its sample planes
+     * live there */
+    std::vector<int> devs = device_list();
+    qr_scene_view v;
+    rc = qr_scene_view_init(&v, c.blob.data(), c.blob.size());
+    if (rc != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc) + ")");
+    if (v.frame->pt_on) devs.resize(1);
+    const int n_dev = (int)devs.size();
+    const int want_blocks = n_dev * (n_dev >= QR_DROPIN_BLOCKS ? 1 : QR_DROPIN_BLOCKS / n_dev);
 
     /* host passes (skipped when nothing changed since this thread's last call) */
-    const bool same = c.resident && c.device == dev && c.blob.size() == c.last_blob.size()
+    const bool same = c.compiled && c.compiled_blocks == want_blocks && c.blob.size() == c.last_blob.size()
                    && memcmp(c.blob.data(), c.last_blob.data(), c.blob.size()) == 0;
     if (!same)
     {
-        c.resident = false;
-        qr_scene_view v;
-        rc = qr_scene_view_init(&v, c.blob.data(), c.blob.size());
-        if (rc != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc) + ")");
+        c.compiled = false;
+        for (int j = 0; j < QR_MAX_DEVICES; j++) c.slot[j].resident = false;
         rc = qr_snapshot_validate(v, err);
         if (rc != QR_OK) return qr_fail(rc, err);
         static thread_local std::vector<BSphere> bsph;
@@ -986,33 +1246,60 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         static const bool rebin = []() { const char *v = getenv("QR_REBIN"); return v && atoi(v) != 0; }();
         if (rebin)
         {
-            rc = pick_device(dev);
+            rc = pick_device(devs[0]);
             if (rc != QR_OK) return rc;
             rc = rebin_tiles(v, bsph, frm, E, T);
             if (rc != QR_OK) return rc;
         }
-        rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, QR_DROPIN_BLOCKS);
+        rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, want_blocks);
         if (rc != QR_OK) return qr_fail(rc, err);
     }
     const double t2 = now_ms();
     const qr_frame &fr = c.prog.frm;
     const int w = fr.frm_w, h = fr.frm_h;
     const size_t frame_bytes = (size_t)w * h * 4;
-    rc = dropin_prepare(c, dev, c.prog.blob.size(), frame_bytes, c.prog.n_sched);
+    const int K = (int)c.prog.block_first.size() - 1;          /* fewer than asked for on a frame of few tile rows */
+    const int bps = (K + n_dev - 1) / n_dev;                   /* blocks per slot: block k belongs to slot k / bps */
+    if (K < 1 || bps > QR_DROPIN_BLOCKS) return qr_fail(QR_ERR_ARG, "schedule blocks do not match the device list");
+    /* slots in use: entry j of the list; slots beyond the list release what they hold */
+    for (int j = 0; j < n_dev; j++)
+    {
+        rc = slot_prepare(c.slot[j], devs[(size_t)j], c.prog.blob.size(), frame_bytes, c.prog.n_sched);
+        if (rc != QR_OK) return rc;
+    }
+    for (int j = n_dev; j < c.n_slots; j++)
+        if (c.slot[j].device >= 0) { if (hipSetDevice(c.slot[j].device) == hipSuccess) slot_release(c.slot[j]); c.slot[j] = DropSlot(); }
+    c.n_slots = n_dev;
+    const size_t span = frame_span(w, h, row_pixels);
+    const bool pinned = span != 0 && frame_is_pinned(frame_host, span);
+    rc = dropin_host_buffers(c, c.prog.blob.size(), pinned ? 0 : frame_bytes);
     if (rc != QR_OK) return rc;
     if (!same)
     {
         memcpy(c.h_stage, c.prog.blob.data(), c.prog.blob.size());
-        HIP_TRY(hipMemcpyAsync(c.d_blob, c.h_stage, c.prog.blob.size(), hipMemcpyHostToDevice, c.sk));
         c.last_blob.swap(c.blob);
-        c.resident = true;
+        c.compiled = true; c.compiled_blocks = want_blocks;
     }
+    hipError_t e = hipSuccess;
+    for (int j = 0; j < n_dev && e == hipSuccess; j++)
+    {
+        DropSlot &sl = c.slot[j];
+        e = hipSetDevice(sl.device);
+        if (e == hipSuccess && !sl.resident)
+        {
+            e = hipMemcpyAsync(sl.d_blob, c.h_stage, c.prog.blob.size(), hipMemcpyHostToDevice, sl.sk);
+            sl.resident = e == hipSuccess;
+        }
+        if (e == hipSuccess) e = hipEventRecord(sl.ev_up, sl.sk);
+    }
+    if (e != hipSuccess) { for (int j = 0; j < n_dev; j++) c.slot[j].resident = false; return qr_fail(QR_ERR_DEVICE, std::string("qr_render0 upload: ") + hipGetErrorString(e)); }
     const double t3 = now_ms();
 
     DropInPt ptio; PtParams pt = {};
     if (fr.pt_on)
     {
-        rc = dropin_pt_begin(c, s_inf, abi, fr, ptio, pt);
+        HIP_TRY(hipSetDevice(c.slot[0].device));
+        rc = dropin_pt_begin(c.slot[0], s_inf, abi, fr, ptio, pt);
         if (rc != QR_OK) return rc;
     }
     else
@@ -1024,73 +1311,79 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     }
 
     LaunchP lp = {};
-    lp.B = (const char *)c.d_blob;
     lp.depth = fr.depth > QR_MAX_DEPTH ? QR_MAX_DEPTH : fr.depth;
     lp.index = fr.index; lp.thnum = fr.thnum > 0 ? fr.thnum : 1;
     lp.group_first = 0; lp.group_stride = 1;
-    lp.stats = c.d_counters + 4;
-    const uint32_t *d_order = (const uint32_t *)((const char *)c.d_blob + c.prog.off_order);
-    const int K = (int)c.prog.block_first.size() - 1;
     /* kernel instance as for uploaded scenes: QR_DIV=0 / 1 forces it (experiments, tests); shadow grids need the per-lane one */
     static const int force_div = []() { const char *dv = getenv("QR_DIV"); return dv ? (atoi(dv) != 0 ? 1 : 0) : -1; }();
     const bool divk = (force_div >= 0 ? force_div != 0 : c.prog.has_long_lists) || c.prog.has_grids;
-    hipError_t e = hipSuccess;
-    /* QR_DROPIN_STREAMS=n: blocks on n streams in turn (1: one after the other) */
+    /* QR_DROPIN_STREAMS=n: a slot's blocks on n streams in turn (1: one after the other) */
     static const int n_streams = []() { const char *v = getenv("QR_DROPIN_STREAMS"); const int n = v ? atoi(v) : QR_DROPIN_STREAMS;
                                         return n < 1 ? 1 : (n > QR_DROPIN_BLOCKS ? QR_DROPIN_BLOCKS : n); }();
-    e = hipEventRecord(c.ev_up, c.sk);
     for (int k = 0; k < K && e == hipSuccess; k++)
     {
-        hipStream_t sk = c.sx[k % n_streams];
-        if (sk != c.sk) e = hipStreamWaitEvent(sk, c.ev_up, 0);
+        DropSlot &sl = c.slot[k / bps];
+        const int kk = k % bps;
+        e = hipSetDevice(sl.device);
+        if (e != hipSuccess) break;
+        hipStream_t sk = sl.sx[kk % n_streams];
+        if (sk != sl.sk) e = hipStreamWaitEvent(sk, sl.ev_up, 0);
         if (e != hipSuccess) break;
         const uint32_t e0 = c.prog.block_first[k], e1 = c.prog.block_first[k + 1];
-        lp.order = d_order + 2 * (size_t)e0;
+        lp.B = (const char *)sl.d_blob;
+        lp.stats = sl.d_counters + 4;
+        lp.order = (const uint32_t *)((const char *)sl.d_blob + c.prog.off_order) + 2 * (size_t)e0;
         lp.n_blocks = (int32_t)(e1 - e0);
         lp.row_begin = (int32_t)c.prog.block_row[k]; lp.row_end = (int32_t)c.prog.block_row[k + 1];
         if (lp.n_blocks > 0)
         {
             if (fr.pt_on)
                 hipLaunchKernelGGL(qr_render_pt_kernel, dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
-                                   lp, pt, (uint32_t *)c.d_frame, c.d_counters);
+                                   lp, pt, (uint32_t *)sl.d_frame, sl.d_counters);
             else if (divk)
                 hipLaunchKernelGGL((qr_render_kernel<false, QR_DIVK_WAVES, true>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
-                                   lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
+                                   lp, (uint32_t *)sl.d_frame, (int32_t *)nullptr, sl.d_counters);
             else
                 hipLaunchKernelGGL((qr_render_kernel<false, 4, false>), dim3((unsigned)lp.n_blocks), dim3(QR_BLOCK), 0, sk,
-                                   lp, (uint32_t *)c.d_frame, (int32_t *)nullptr, c.d_counters);
+                                   lp, (uint32_t *)sl.d_frame, (int32_t *)nullptr, sl.d_counters);
         }
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(c.ev_k[k], sk);
-        /* copy block k back as soon as it is rendered, on the copy stream */
-        if (e == hipSuccess) e = hipStreamWaitEvent(c.sc, c.ev_k[k], 0);
-        const size_t off = (size_t)lp.row_begin * w, n = (size_t)(lp.row_end - lp.row_begin) * w * 4;
-        if (e == hipSuccess && n > 0) e = hipMemcpyAsync(c.h_frame + off, (const uint32_t *)c.d_frame + off, n, hipMemcpyDeviceToHost, c.sc);
-        if (e == hipSuccess) e = hipEventRecord(c.ev_c[k], c.sc);
+        if (e == hipSuccess) e = hipEventRecord(sl.ev_k[kk], sk);
+        /* copy block k back as soon as it is rendered, on the slot's copy stream: into the caller's registered frame, or
+         * into the staging frame */
+        if (e == hipSuccess) e = hipStreamWaitEvent(sl.sc, sl.ev_k[kk], 0);
+        if (e == hipSuccess)
+        {
+            if (pinned) e = copy_rows_direct(frame_host, row_pixels, (const uint32_t *)sl.d_frame, w, lp.row_begin, lp.row_end, lp.index, lp.thnum, sl.sc);
+            else if (lp.row_end > lp.row_begin)
+                e = hipMemcpyAsync(c.h_frame + (size_t)lp.row_begin * w, (const uint32_t *)sl.d_frame + (size_t)lp.row_begin * w,
+                                   (size_t)(lp.row_end - lp.row_begin) * w * 4, hipMemcpyDeviceToHost, sl.sc);
+        }
+        if (e == hipSuccess) e = hipEventRecord(sl.ev_c[kk], sl.sc);
     }
-    if (fr.pt_on)
-        for (int k = 0; k < K && e == hipSuccess; k++) e = hipStreamWaitEvent(c.sk, c.ev_k[k], 0);   /* the planes go back when every block is done */
-    if (fr.pt_on && e == hipSuccess) e = dropin_pt_end(c, ptio);    /* the planes with this frame's sample go back to the engine */
+    if (fr.pt_on && e == hipSuccess)
+    {
+        DropSlot &sl = c.slot[0];
+        for (int k = 0; k < K && e == hipSuccess; k++) e = hipStreamWaitEvent(sl.sk, sl.ev_k[k % bps], 0);   /* the planes go back when every block is done */
+        if (e == hipSuccess) e = dropin_pt_end(sl, ptio);    /* the planes with this frame's sample go back to the engine */
+    }
     const double t4 = now_ms();
     /* the host moves finished blocks into the caller's frame: only the rows this call owns (index / thnum),
-     * honouring a negative stride (bottom-up frames, engine.cpp:2814-2850) */
+     * honouring a negative stride (bottom-up frames, engine.cpp:2814-2850); a registered frame only waits for its copies */
     for (int k = 0; k < K && e == hipSuccess; k++)
     {
-        e = hipEventSynchronize(c.ev_c[k]);
+        e = hipEventSynchronize(c.slot[k / bps].ev_c[k % bps]);
         if (e != hipSuccess) break;
-        const int y0 = (int)c.prog.block_row[k], y1 = (int)c.prog.block_row[k + 1];
-        if (lp.thnum <= 1 && row_pixels == w)
-            copy_streaming(frame_host + (size_t)y0 * w, c.h_frame + (size_t)y0 * w, (size_t)(y1 - y0) * w * 4);
-        else
-            for (int y = y0; y < y1; y++)
-            {
-                if (lp.thnum > 1 && (y % lp.thnum) != lp.index) continue;
-                memcpy(frame_host + (ptrdiff_t)y * row_pixels, c.h_frame + (size_t)y * w, (size_t)w * 4);
-            }
+        if (!pinned) copy_rows_host(frame_host, row_pixels, c.h_frame, w, (int)c.prog.block_row[k], (int)c.prog.block_row[k + 1], lp.index, lp.thnum);
     }
-    if (e != hipSuccess) { c.resident = false; return qr_fail(QR_ERR_DEVICE, std::string("qr_render0: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess)
+    {
+        for (int j = 0; j < n_dev; j++) c.slot[j].resident = false;
+        return qr_fail(QR_ERR_DEVICE, std::string("qr_render0: ") + hipGetErrorString(e));
+    }
     if (verbose)
-        fprintf(stderr, "qr_render0: flatten %.3f ms (%zu bytes), validate+compile %.3f ms%s, stage+upload %.3f ms (%zu bytes), launches %.3f ms, wait+copy-back %.3f ms\n",
-                t1 - t0, c.last_blob.size(), t2 - t1, same ? " (unchanged scene: skipped)" : "", t3 - t2, c.prog.blob.size(), t4 - t3, now_ms() - t4);
+        fprintf(stderr, "qr_render0: flatten %.3f ms (%zu bytes), validate+compile %.3f ms%s, stage+upload %.3f ms (%zu bytes), launches %.3f ms, wait+copy-back %.3f ms%s, %d device slot%s\n",
+                t1 - t0, c.last_blob.size(), t2 - t1, same ? " (unchanged scene: skipped)" : "", t3 - t2, c.prog.blob.size(), t4 - t3, now_ms() - t4,
+                pinned ? " (registered frame: direct)" : "", n_dev, n_dev == 1 ? "" : "s");
     return QR_OK;
 }

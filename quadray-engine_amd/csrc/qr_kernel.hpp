@@ -63,7 +63,7 @@
 #define QR_KNOB(bit) false
 #endif
 #define QR_PER_LANE_TILE 0xFFFFFFFEu /* schedule entry: the footprint straddles tiles, look the list up per pixel (QR_SCHED_PER_LANE) */
-#define QR_WT_SLOTS 12       /* QR_WAVETIME builds: u64 slots per wave */
+#define QR_WT_SLOTS 14       /* QR_WAVETIME builds: u64 slots per wave */
 #ifndef QR_MIN_WAVES_PER_SIMD
 #define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
 #endif
@@ -225,6 +225,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
 {
 #ifdef QR_WAVETIME
     const unsigned long long wt_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wt_clk0 = __builtin_amdgcn_s_memtime();      /* shader cycles: with the 100 MHz stamps, the clock the wave ran at */
     qr_wt_groups[0] = 0; qr_wt_groups[1] = 0; qr_wt_shadow = 0; qr_wt_cells[0] = qr_wt_cells[1] = qr_wt_cells[2] = qr_wt_cells[3] = 0;
     unsigned long long wt_mid = 0, wt_trav = 0, wt_shade = 0, wt_t0 = 0; u32 wt_push = 0;
 #endif
@@ -602,6 +603,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     {
         unsigned long long *o = counters + 64 + (size_t)gw * QR_WT_SLOTS;
         o[0] = wt_start; o[1] = wt_mid; o[2] = __builtin_amdgcn_s_memrealtime();
+        o[12] = wt_clk0; o[13] = __builtin_amdgcn_s_memtime();
         o[4] = ord; o[5] = qr_wt_groups[0]; o[6] = qr_wt_groups[1]; o[7] = wt_push; o[8] = wt_trav; o[9] = wt_shade; o[10] = qr_wt_shadow;
         o[11] = (unsigned long long)qr_wt_cells[0] | ((unsigned long long)qr_wt_cells[1] << 16) | ((unsigned long long)qr_wt_cells[2] << 32) | ((unsigned long long)qr_wt_cells[3] << 48);
         o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))

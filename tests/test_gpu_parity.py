@@ -192,17 +192,18 @@ def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
     tmp = tempfile.mkdtemp(prefix="qrdropb_")
     os.makedirs(os.path.join(tmp, "dump"), exist_ok=True)
     report = []
-    for extra in ([], ["--animate", "33"]):
+    for extra in ([], ["--animate", "33"], ["--pin-frame"], ["--animate", "33", "--pin-frame"]):
         out = subprocess.run([exe, "--scene", "demo01", "-w", "1920", "-h", "1080", "--gpu", "--bench", "50"] + extra,
                              cwd=tmp, capture_output=True, text=True, timeout=600, env=dict(os.environ, QR_VERBOSE="1"))
         assert out.returncode == 0, out.stdout + out.stderr
         assert "MATCH" in out.stdout and "MISMATCH" not in out.stdout, out.stdout
-        if extra:
+        if "--animate" in extra:
             assert "ANIM_MATCH" in out.stdout, out.stdout
         line = [l for l in out.stdout.splitlines() if l.startswith("gpu_bench")][0]
         cpu = [l for l in out.stdout.splitlines() if l.startswith("bench ")][0]
-        split = [l for l in out.stderr.splitlines() if l.startswith("qr_render0:")][-1]
-        report += [cpu, line, split]
+        # the split of a frame of the timed loop (the last two calls of an animated run re-render one scene time)
+        split = [l for l in out.stderr.splitlines() if l.startswith("qr_render0:")][-3 if "--animate" in extra else -1]
+        report += [" ".join(extra) or "(frozen)", cpu, line, split]
         assert float(re.search(r"median_ms ([0-9.]+)", line).group(1)) < 5.0
     with capsys.disabled():
         print("\n" + "\n".join(report))

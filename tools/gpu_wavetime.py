@@ -22,8 +22,14 @@ if len(sys.argv) > 2:
     scn.set_depth(int(sys.argv[2]))
 f = scn.new_frame()
 scn.render(f); torch.cuda.synchronize()
+import time
+t_w = time.time()
+while time.time() - t_w < 2.0:                       # two seconds of back-to-back launches first: the clock the chip settles at
+    for _ in range(50):
+        scn.render(f)
+    torch.cuda.synchronize()
 avg, mn = scn.render_timed(f, 5)
-w = np.fromfile(out, dtype=np.uint64).reshape(-1, 12)
+w = np.fromfile(out, dtype=np.uint64).reshape(-1, 14)
 w = w[w[:, 2] != 0]
 t0 = int(w[:, 0].min())
 st = (w[:, 0].astype(np.int64) - t0) / 100.0          # us
@@ -32,6 +38,14 @@ en = (w[:, 2].astype(np.int64) - t0) / 100.0
 dur = en - st
 walks = (w[:, 3] >> np.uint64(40)).astype(np.int64)
 print(f"{sys.argv[1]}: kernel {avg*1e3:.1f} us; waves {len(w)}; last wave ends at {en.max():.1f} us")
+# in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles / 100 MHz ticks over each wave's life, waves of >= 5 us
+cyc = (w[:, 13].astype(np.int64) - w[:, 12].astype(np.int64)); tk = (w[:, 2].astype(np.int64) - w[:, 0].astype(np.int64))
+m = tk >= 500
+if m.any():
+    clk = cyc[m] / tk[m] * 100.0
+    print("in-kernel clock MHz over waves >= 5 us: p10 %.0f p50 %.0f p90 %.0f (%d waves)" % (*np.percentile(clk, [10, 50, 90]), int(m.sum())))
+print("whole launch: first stamp to last stamp %.1f us, %.0f MHz" % ((w[:, 2].max() - w[:, 0].min()) / 100.0,
+      (int(w[:, 13].max()) - int(w[:, 12].min())) / max(1, int(w[:, 2].max()) - int(w[:, 0].min())) * 100.0))
 print("wave duration us: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(dur, [10, 50, 90, 99, 100])))
 print("first traverse (start->after) us: p50 %.1f p90 %.1f" % tuple(np.percentile(mid - st, [50, 90])))
 print("non-shadow walks per wave: mean %.2f max %d; waves with >1: %d" % (walks.mean(), walks.max(), (walks > 1).sum()))
