@@ -366,6 +366,12 @@ struct Builder
     uint32_t srf_off(int si) const { return o_srf + (uint32_t)si * (uint32_t)sizeof(DSurf); }
 
     /* ---- surface lists ---- */
+    /* chains compiled so far by content (see compile_list) */
+    struct DedupEnt { size_t first, len; uint32_t off; uint8_t heavy; };
+    std::unordered_multimap<uint64_t, DedupEnt> dedup_map;
+    std::vector<int32_t> dedup_pool, dk;
+    bool dedup_on = !(getenv("QR_LIST_DEDUP") && atoi(getenv("QR_LIST_DEDUP")) == 0);      /* QR_LIST_DEDUP=0: one program per chain (A/B) */
+
     uint32_t compile_list(int head)
     {
         if (head == QR_NULL) return 0;
@@ -385,6 +391,38 @@ struct Builder
             ch.push_back(Tmp{e, 0, E[e].simd, QR_NULL, true});
         }
         const int n = (int)ch.size();
+        /* The engine hands every screen tile a chain of its own, and most neighbours hold the same surfaces in the same order:
+         * a chain whose elements (surface, kind, position of the array's last member) equal those of a chain compiled
+         * before IS that program -- the cells depend on nothing else.  One copy: a third of the compile time at 1080p, and
+         * the waves of a frame read a few hundred list programs through the scalar cache instead of tens of thousands. */
+        uint64_t dkey = 1469598103934665603ull;
+        bool dedup = dedup_on;
+        dk.clear();
+        for (int i = 0; i < n && dedup; i++)
+        {
+            const qr_elem &el = E[ch[i].e];
+            int rel = -1;
+            if (el.data != QR_NULL)
+            {
+                if (el.data < 0 || (size_t)el.data >= chain_stamp.size() || chain_stamp[el.data] != stamp) { dedup = false; break; }
+                rel = chain_pos[el.data];
+            }
+            const int32_t w3[3] = { el.simd, el.kind, rel };
+            for (int k = 0; k < 3; k++) { dk.push_back(w3[k]); dkey = (dkey ^ (uint32_t)w3[k]) * 1099511628211ull; }
+        }
+        if (dedup)
+        {
+            auto range = dedup_map.equal_range(dkey);
+            for (auto it = range.first; it != range.second; ++it)
+            {
+                const DedupEnt &d = it->second;
+                if (d.len == dk.size() && memcmp(dedup_pool.data() + d.first, dk.data(), dk.size() * sizeof(int32_t)) == 0)
+                {
+                    list_off[head] = d.off; list_heavy[head] = d.heavy;
+                    return d.off;
+                }
+            }
+        }
         lo_after.assign((size_t)n, QR_NULL); lo_self.assign((size_t)n, QR_NULL);
         /* box cull cells (QR_OPF_BOX) only in images whose lists are all short: the packet-walk kernel instance serves them */
         const bool list_boxes = box_ok;
@@ -634,6 +672,12 @@ struct Builder
         if (want_dda && world && (lf & QR_LISTF_DIV)) { build_dda(base, off, n); lf |= QR_LISTF_DDA; any_long = true; }
         list_off[head] = off | lf;
         list_heavy[head] = heavy;
+        if (dedup)
+        {
+            DedupEnt d = { dedup_pool.size(), dk.size(), off | lf, heavy };
+            dedup_pool.insert(dedup_pool.end(), dk.begin(), dk.end());
+            dedup_map.emplace(dkey, d);
+        }
         return off | lf;
     }
 
@@ -889,7 +933,7 @@ struct Builder
 } // namespace
 
 int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
-                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks)
+                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks, bool verify)
 {
     static const bool timing = getenv("QR_COMPILE_TIMING") != nullptr;
     struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -1158,6 +1202,7 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
     tick("finish");
+    if (!verify) return QR_OK;
     const int vrc = qr_program_verify(out, err);
     tick("verify");
     return vrc;

@@ -1020,6 +1020,7 @@ struct DropIn
     QrProgram prog;
     bool compiled = false;              /* prog is the program of last_blob ... */
     int compiled_blocks = 0;            /* ... with its schedule grouped for this many row blocks */
+    QrProgramStats verified = {}; int verified_blocks = 0;     /* layout of the last image qr_program_verify walked */
 };
 static thread_local DropIn g_drop;
 
@@ -1251,8 +1252,22 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
             rc = rebin_tiles(v, bsph, frm, E, T);
             if (rc != QR_OK) return rc;
         }
-        rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, want_blocks);
+        /* the finished image is verified offset by offset (qr_program_verify, a third of the compile time at 1080p) when its
+         * structure differs from the last image this thread verified -- the first frame, and whenever lists or cells come
+         * or go; an animation that only moves things yields the same layout from the same code path.  QR_VERIFY=1: always,
+         * 0: never */
+        static const int verify_env = []() { const char *e = getenv("QR_VERIFY"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, want_blocks, false);
         if (rc != QR_OK) return qr_fail(rc, err);
+        const QrProgramStats &ps = c.prog.stats;
+        const bool changed = ps.bytes != c.verified.bytes || ps.n_lists != c.verified.n_lists || ps.n_cells != c.verified.n_cells
+                          || ps.n_clip_cells != c.verified.n_clip_cells || ps.n_dropped != c.verified.n_dropped || c.verified_blocks != want_blocks;
+        if (verify_env == 1 || (verify_env < 0 && changed))
+        {
+            rc = qr_program_verify(c.prog, err);
+            if (rc != QR_OK) return qr_fail(rc, err);
+            c.verified = ps; c.verified_blocks = want_blocks;
+        }
     }
     const double t2 = now_ms();
     const qr_frame &fr = c.prog.frm;

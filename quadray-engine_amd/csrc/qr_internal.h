@@ -51,7 +51,8 @@ int  qr_snapshot_validate(const qr_scene_view &v, std::string &err);
 void qr_bound_spheres(const qr_scene_view &v, std::vector<BSphere> &out);
 /* E / T: list cells and tile heads (the snapshot's, or the ones the binning pass built); frm: frame record to use */
 int  qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
-                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks = 0);
+                      const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks = 0,
+                      bool verify = true);      /* verify: walk every offset of the finished image (qr_program_verify) before returning it */
 int  qr_program_verify(const QrProgram &p, std::string &err);
 /* per-surface shadow / reflection / light lists from the global list and the surfaces' bounds (ssort / lsort's role) */
 int  qr_snapshot_build_lists(const qr_scene_view &v, std::vector<uint8_t> &out, std::string &err);

@@ -14,6 +14,8 @@ if os.environ.get("QR_LIB") != LIB:
     sys.stdout.write(p.stdout)
     for l in bad:
         print(l)
+    if p.returncode != 0:
+        print("child failed:\n" + p.stderr[-3000:])
     sys.exit(1 if (p.returncode != 0 or bad) else 0)
 
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
