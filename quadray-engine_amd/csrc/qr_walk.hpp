@@ -638,6 +638,151 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
  * OO_cyc for the lanes of a wave that share the list program at `head` (wave-uniform, not 0).
  * SHADOW: any-hit walk, ends as soon as every ray is occluded.
  */
+#ifndef QR_ASM_CULL
+#define QR_ASM_CULL 1       /* 0: the run of culled cells as compiled C++ (the statistics / guard builds always use that form) */
+#endif
+
+/*
+ * The run of culled cells of walk_list, written out: load a cell, leave unless it is a solver cell with a cull bound, test the
+ * bound (box slabs or sphere, the arithmetic of the C++ form below), leave if some ray that is on needs the cell, step.
+ * hipcc 7.2 compiles the C++ loop to 25 scalar instructions a cell (structured-control-flow bookkeeping: s_mov -1 / s_andn2 vcc,
+ * exec / s_cbranch_vccnz chains) around 19 vector ones; a third of a frame's instructions are scalar and two thirds of those
+ * sat in this loop.  Here a culled cell costs 12-14 scalar instructions.  The cell lives in s[88:95] (an inline-asm operand
+ * has no sub-register syntax, and the fields are needed one by one), scratch masks in s[96:99]; the cell is handed out in
+ * four 64-bit operands when the run ends.
+ * Box test: miss <=> tn > tf | tf < 0 | tn > tb1 with tb1 = 1.00001 * depth bound >= 0, folded into ONE compare:
+ * max(tn, 0) > min(tf, tb1)  (max / min drop a NaN operand exactly where the three compares were false).
+ */
+template <bool BOXC>
+__device__ __forceinline__ void cull_run(BaseP B, u32 &pos, u32x8 &c, const Ray &r, const WalkState &w,
+                                         float idx, float idy, float idz, float nox, float noy, float noz, float dd, float dde, float dlen)
+{
+    unsigned long long c01, c23, c45, c67;
+    float t0, t1, t2, t3, t4, t5, t6;
+    const float tb1 = w.tbuf * 1.00001f;
+    u32 cur = __builtin_amdgcn_readfirstlane(pos);           /* wave-uniform by construction; says so to the compiler */
+    if constexpr (BOXC)
+    {
+        asm volatile(
+            "qr_cull_top_%=:\n"
+            "s_load_dwordx8 s[88:95], %[B], %[pos] offset:0x0\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_and_b32 s96, s88, 40\n"                      /* QR_OPF_CULL | QR_OPT_BV */
+            "s_cmp_lg_u32 s96, 32\n"
+            "s_cbranch_scc1 qr_cull_out_%=\n"
+            "s_bitcmp0_b32 s88, 19\n"                       /* QR_OPF_BOX */
+            "s_cbranch_scc1 qr_cull_sph_%=\n"
+            "v_fma_f32 %[t0], s90, %[idx], %[nox]\n"
+            "v_fma_f32 %[t1], s93, %[idx], %[nox]\n"
+            "v_fma_f32 %[t2], s91, %[idy], %[noy]\n"
+            "v_fma_f32 %[t3], s94, %[idy], %[noy]\n"
+            "v_fma_f32 %[t4], s92, %[idz], %[noz]\n"
+            "v_fma_f32 %[t5], s95, %[idz], %[noz]\n"
+            "v_min_f32 %[t6], %[t0], %[t1]\n"
+            "v_max_f32 %[t0], %[t0], %[t1]\n"
+            "v_min_f32 %[t1], %[t2], %[t3]\n"
+            "v_max_f32 %[t2], %[t2], %[t3]\n"
+            "v_min_f32 %[t3], %[t4], %[t5]\n"
+            "v_max_f32 %[t4], %[t4], %[t5]\n"
+            "v_max3_f32 %[t6], %[t6], %[t1], %[t3]\n"
+            "v_min3_f32 %[t0], %[t0], %[t2], %[t4]\n"
+            "v_max_f32 %[t6], 0, %[t6]\n"
+            "v_min_f32 %[t0], %[t0], %[tb1]\n"
+            "v_cmp_gt_f32 vcc, %[t6], %[t0]\n"
+            "qr_cull_tst_%=:\n"
+            "v_cmp_ne_u32 s[96:97], s89, %[osrf]\n"
+            "s_and_b64 s[96:97], vcc, s[96:97]\n"
+            "v_cmp_ge_u32 vcc, %[pos], %[res]\n"
+            "s_andn2_b64 s[96:97], vcc, s[96:97]\n"         /* rays that are on and not provably missed (or whose own surface it is) */
+            "s_cbranch_scc1 qr_cull_out_%=\n"
+            "s_add_u32 %[pos], %[pos], 32\n"
+            "s_branch qr_cull_top_%=\n"
+            "qr_cull_sph_%=:\n"
+            "v_sub_f32 %[t0], s92, %[ox]\n"
+            "v_sub_f32 %[t1], s93, %[oy]\n"
+            "v_sub_f32 %[t2], s94, %[oz]\n"
+            "v_mul_f32 %[t3], %[t0], %[dx]\n"
+            "v_mul_f32 %[t4], %[t0], %[t0]\n"
+            "v_fmac_f32 %[t3], %[t1], %[dy]\n"
+            "v_fmac_f32 %[t4], %[t1], %[t1]\n"
+            "v_fmac_f32 %[t3], %[t2], %[dz]\n"
+            "v_fmac_f32 %[t4], %[t2], %[t2]\n"
+            "v_subrev_f32 %[t0], s90, %[t4]\n"
+            "v_mul_f32_e64 %[t1], %[t3], |%[t3]|\n"
+            "v_cmp_lt_f32 vcc, s91, %[t4]\n"
+            "v_fmac_f32 %[t1], %[t4], %[dde]\n"
+            "v_mul_f32 %[t0], %[dd], %[t0]\n"
+            "v_fma_f32 %[t2], -s95, %[dlen], %[t3]\n"
+            "v_cmp_lt_f32 s[96:97], %[t1], %[t0]\n"
+            "v_cmp_gt_f32 s[98:99], %[t2], %[tbd]\n"
+            "s_and_b64 vcc, vcc, s[96:97]\n"
+            "s_or_b64 vcc, vcc, s[98:99]\n"
+            "s_branch qr_cull_tst_%=\n"
+            "qr_cull_out_%=:\n"
+            "s_mov_b64 %[c01], s[88:89]\n"
+            "s_mov_b64 %[c23], s[90:91]\n"
+            "s_mov_b64 %[c45], s[92:93]\n"
+            "s_mov_b64 %[c67], s[94:95]\n"
+            : [c01] "=&s"(c01), [c23] "=&s"(c23), [c45] "=&s"(c45), [c67] "=&s"(c67), [pos] "+s"(cur),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6)
+            : [B] "s"(B), [idx] "v"(idx), [idy] "v"(idy), [idz] "v"(idz), [nox] "v"(nox), [noy] "v"(noy), [noz] "v"(noz), [tb1] "v"(tb1),
+              [ox] "v"(r.org.x), [oy] "v"(r.org.y), [oz] "v"(r.org.z), [dx] "v"(r.dir.x), [dy] "v"(r.dir.y), [dz] "v"(r.dir.z),
+              [dd] "v"(dd), [dde] "v"(dde), [dlen] "v"(dlen), [tbd] "v"(w.tbd), [res] "v"(w.resume), [osrf] "v"(r.osrf)
+            : "vcc", "scc", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    }
+    else
+    {
+        (void)idx; (void)idy; (void)idz; (void)nox; (void)noy; (void)noz; (void)tb1; (void)t5; (void)t6;
+        asm volatile(
+            "qr_cull_top_%=:\n"
+            "s_load_dwordx8 s[88:95], %[B], %[pos] offset:0x0\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_and_b32 s96, s88, 0x80028\n"                 /* QR_OPF_CULL | QR_OPT_BV | QR_OPF_BOX: a box cell is not culled here */
+            "s_cmp_lg_u32 s96, 32\n"
+            "s_cbranch_scc1 qr_cull_out_%=\n"
+            "v_sub_f32 %[t0], s92, %[ox]\n"
+            "v_sub_f32 %[t1], s93, %[oy]\n"
+            "v_sub_f32 %[t2], s94, %[oz]\n"
+            "v_mul_f32 %[t3], %[t0], %[dx]\n"
+            "v_mul_f32 %[t4], %[t0], %[t0]\n"
+            "v_fmac_f32 %[t3], %[t1], %[dy]\n"
+            "v_fmac_f32 %[t4], %[t1], %[t1]\n"
+            "v_fmac_f32 %[t3], %[t2], %[dz]\n"
+            "v_fmac_f32 %[t4], %[t2], %[t2]\n"
+            "v_subrev_f32 %[t0], s90, %[t4]\n"
+            "v_mul_f32_e64 %[t1], %[t3], |%[t3]|\n"
+            "v_cmp_lt_f32 vcc, s91, %[t4]\n"
+            "v_fmac_f32 %[t1], %[t4], %[dde]\n"
+            "v_mul_f32 %[t0], %[dd], %[t0]\n"
+            "v_fma_f32 %[t2], -s95, %[dlen], %[t3]\n"
+            "v_cmp_lt_f32 s[96:97], %[t1], %[t0]\n"
+            "v_cmp_gt_f32 s[98:99], %[t2], %[tbd]\n"
+            "s_and_b64 vcc, vcc, s[96:97]\n"
+            "s_or_b64 vcc, vcc, s[98:99]\n"
+            "v_cmp_ne_u32 s[96:97], s89, %[osrf]\n"
+            "s_and_b64 s[96:97], vcc, s[96:97]\n"
+            "v_cmp_ge_u32 vcc, %[pos], %[res]\n"
+            "s_andn2_b64 s[96:97], vcc, s[96:97]\n"
+            "s_cbranch_scc1 qr_cull_out_%=\n"
+            "s_add_u32 %[pos], %[pos], 32\n"
+            "s_branch qr_cull_top_%=\n"
+            "qr_cull_out_%=:\n"
+            "s_mov_b64 %[c01], s[88:89]\n"
+            "s_mov_b64 %[c23], s[90:91]\n"
+            "s_mov_b64 %[c45], s[92:93]\n"
+            "s_mov_b64 %[c67], s[94:95]\n"
+            : [c01] "=&s"(c01), [c23] "=&s"(c23), [c45] "=&s"(c45), [c67] "=&s"(c67), [pos] "+s"(cur),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
+            : [B] "s"(B),
+              [ox] "v"(r.org.x), [oy] "v"(r.org.y), [oz] "v"(r.org.z), [dx] "v"(r.dir.x), [dy] "v"(r.dir.y), [dz] "v"(r.dir.z),
+              [dd] "v"(dd), [dde] "v"(dde), [dlen] "v"(dlen), [tbd] "v"(w.tbd), [res] "v"(w.resume), [osrf] "v"(r.osrf)
+            : "vcc", "scc", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    }
+    pos = cur;
+    c.s0 = (u32)c01; c.s1 = (u32)(c01 >> 32); c.s2 = (u32)c23; c.s3 = (u32)(c23 >> 32);
+    c.s4 = (u32)c45; c.s5 = (u32)(c45 >> 32); c.s6 = (u32)c67; c.s7 = (u32)(c67 >> 32);
+}
+
 /* BOXC: the walk knows box cull cells (QR_OPF_BOX).  The kernel instance with the per-lane walks is compiled without: images it
  * serves carry none (qr_compile.cpp), and when it is forced onto one (QR_DIV=1) such a cell is simply not culled */
 template <bool SHADOW, bool BOXC>
@@ -690,6 +835,9 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
          * the walk's only cell load.
          */
         u32x8 c;
+#if QR_ASM_CULL && !defined(QR_STATS) && !defined(QR_PROF) && !defined(QR_WAVETIME) && !defined(QR_GUARD)
+        cull_run<BOXC>(B, pos, c, r, w, idx, idy, idz, nox, noy, noz, dd, dde, dlen);
+#else
         for (;;)
         {
             /* `pos` is wave-uniform by construction; every assignment says so to the compiler (readfirstlane of the
@@ -739,6 +887,7 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
 #endif
             pos = __builtin_amdgcn_readfirstlane(pos + 32);
         }
+#endif
         const u32 op = c.s0;
         if (op == 0) break;
         const u32 srf_off = c.s1;
