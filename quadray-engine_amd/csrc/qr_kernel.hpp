@@ -63,6 +63,9 @@
 #define QR_KNOB(bit) false
 #endif
 #define QR_PER_LANE_TILE 0xFFFFFFFEu /* schedule entry: the footprint straddles tiles, look the list up per pixel (QR_SCHED_PER_LANE) */
+#ifndef QR_DYN_PRIO
+#define QR_DYN_PRIO 1        /* issue priority follows the recursion round a wave is in (0: fixed by the footprint's class) */
+#endif
 #define QR_WT_SLOTS 14       /* QR_WAVETIME builds: u64 slots per wave */
 #ifndef QR_MIN_WAVES_PER_SIMD
 #define QR_MIN_WAVES_PER_SIMD 4   /* __launch_bounds__ 2nd argument: waves per SIMD */
@@ -251,7 +254,14 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     (void)gw;
     /* footprints that can recurse get issue priority: the frame ends with the slowest of them, and while
      * the bulk is in flight they would otherwise share their SIMD's issue slots evenly */
+#if QR_DYN_PRIO
+    /* ... and among them the ones that actually do: every traversal round a wave starts raises its priority (2 waves of demo
+     * scene 1 at 1080p run 7 rounds, 20 run 6, 12 000 one -- but 3 900 footprints CAN recurse and fill the first generation) */
+    if (ord >> 30) __builtin_amdgcn_s_setprio(1);
+    int prio_round = 0;
+#else
     if (ord >> 30) { if ((ord >> 30) >= 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+#endif
     const int px = fsaa == 2 ? (pix & 3) : (pix & 7), py = fsaa == 2 ? (pix >> 2) : (pix >> 3);
     const int x = (int)(ord & 0x3FFFu) * fw + px;
     const int y = (int)((ord >> 14) & 0x3FFFu) * fh + py;
@@ -399,6 +409,9 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             Hit h; bool occ;
 #ifdef QR_WAVETIME
             wt_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if QR_DYN_PRIO
+            if (prio_round < 3) { prio_round++; if (prio_round == 2) __builtin_amdgcn_s_setprio(2); else if (prio_round == 3) __builtin_amdgcn_s_setprio(3); }
 #endif
             /* coherent: every ray of this round is a primary ray (neighbouring pixels) */
             const bool coherent = !any_lane(tr && sp != 0);

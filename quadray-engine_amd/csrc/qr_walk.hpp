@@ -30,6 +30,11 @@ typedef unsigned long long lm_t;
 #define QR_GUARD_POS(tag, p, prev, onbad) do { } while (0)
 #endif
 #define LM(cond) __builtin_amdgcn_ballot_w64(cond)
+#ifndef QR_CLIP_PREFETCH
+#define QR_CLIP_PREFETCH 0  /* 1: clip() loads the next cell of a clipper program while the current one is evaluated.  Measured: no
+                             * change for a band of the slowest footprints rendered alone (92.3 / 92.6 us), 1.6 % slower frames (two
+                             * more spilled scalar registers): the cells of a program share cache lines, the waits are elsewhere */
+#endif
 __device__ __forceinline__ bool lane_of(lm_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ bool any_lane(bool b) { return LM(b) != 0ull; }
 
@@ -262,11 +267,24 @@ __device__ __forceinline__ typename MK<DIV>::T clip(BaseP B, const SurfS &s, u32
         V3 cxyz = {0.0f, 0.0f, 0.0f};                   /* the hit in the cached clipper trnode's space */
         V3 pt = hit;                                    /* what a fast plane cell reads: the world hit, or cxyz while a trnode group lasts */
         u32 cp = s.clip;
+#if QR_CLIP_PREFETCH
+        /* the program's cells lie one behind the other: the next one is on its way while this one is evaluated (a lone
+         * wave in the tail of a frame otherwise waits out one scalar-cache round trip per cell).  The cell behind the END
+         * cell is read and dropped: programs are followed by other sections of the image or its tail padding. */
+        if constexpr (!DIV) cp = __builtin_amdgcn_readfirstlane(cp);
+        u32x8 cn = *(const QR_CONST u32x8 *)(B + cp);
+#endif
         for (;;)
         {
             if constexpr (!DIV) cp = __builtin_amdgcn_readfirstlane(cp);
+#if QR_CLIP_PREFETCH
+            const u32x8 cc = cn;
+            cp += (u32)sizeof(CClip);
+            if (cc.s0 != 0) cn = *(const QR_CONST u32x8 *)(B + cp);
+#else
             const u32x8 cc = *(const QR_CONST u32x8 *)(B + cp);
             cp += (u32)sizeof(CClip);
+#endif
             const u32 cop = cc.s0;
             if (cop == 0) break;
             QR_PROF_HIT(2);             /* clipper cells */
