@@ -221,6 +221,31 @@ __device__ __forceinline__ float clamp1(float x) { return x < 1.0f ? x : 1.0f; }
 struct PtParams { u32 *seeds; float *acc_r, *acc_g, *acc_b; float pts_o, pts_u; int eager, pad; };
 
 /* one wave = one schedule entry: footprint `ord`, its tile-list program, rendered into `frame` */
+/*
+ * The pixel sample a lane stands for and whether this launch owns it, from the schedule word.  Computed where it is needed --
+ * at the start of a wave, in the empty-tile exit, at the final store -- each time through opaque copies of its inputs: as
+ * common subexpressions the coordinates were four registers live across the whole recursion, and the 128-register kernel
+ * instance spilled them (2 KB of scratch traffic per wave: two thirds of the HBM bytes of the deep-recursion frames).
+ */
+__device__ __forceinline__ bool pixel_of(u32 ord, int fsaa, const LaunchP &lp, FrmP fr, int &x, int &y, int &k)
+{
+    asm volatile("" : "+s"(ord));
+    int lane = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(lane));
+    const int fw = fsaa == 2 ? 4 : 8, fh = fsaa == 0 ? 8 : 4;
+    const int pix = lane >> fsaa;               /* pixel index inside the wave */
+    k = lane & ((1 << fsaa) - 1);               /* sample index inside the pixel */
+    const int px = fsaa == 2 ? (pix & 3) : (pix & 7), py = fsaa == 2 ? (pix >> 2) : (pix >> 3);
+    x = (int)(ord & 0x3FFFu) * fw + px;
+    y = (int)((ord >> 14) & 0x3FFFu) * fh + py;
+    const int group = y >> 3;
+    bool inside = x < fr->fr.frm_w && y < fr->fr.frm_h && y >= lp.row_begin && y < lp.row_end;
+    if (group < lp.group_first) inside = false;
+    if (lp.group_stride != 1 && (group - lp.group_first) % lp.group_stride != 0) inside = false;
+    if (inside && lp.thnum > 1) inside = (y % lp.thnum) == lp.index;
+    return inside;
+}
+
 template <bool COUNT, bool DIVK, bool PT = false>
 __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, const u32 sched_head, const int gw,
                                             uint32_t *__restrict__ frame, int32_t *__restrict__ ids,
@@ -277,10 +302,14 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     {
         /* empty tile: no ray of the footprint meets anything; the reference's pipeline ends with
          * colour 0 for such a packet (clamp, sqrt and cvt of 0 are 0), so store it and leave */
-        if (inside && k == 0)
         {
-            frame[(size_t)y * frm_w + x] = 0u;
-            if (ids != nullptr) ids[(size_t)y * frm_w + x] = -1;
+            int x0, y0, k0;
+            const bool in0 = pixel_of(ord, fsaa, lp, fr, x0, y0, k0);
+            if (in0 && k0 == 0)
+            {
+                frame[(size_t)y0 * frm_w + x0] = 0u;
+                if (ids != nullptr) ids[(size_t)y0 * frm_w + x0] = -1;
+            }
         }
         if (COUNT)
         {
@@ -378,6 +407,10 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     ou.mode = inside ? 0 : 2;                   /* 0 trace, 1 return, 2 done */
     ou.ret = {0, 0, 0};
     ou.hit_id = -1;
+    /* the primary hit id is only wanted by id renders and only when the wave ends: it waits in LDS, not in a register that
+     * every frame's waves would carry through the whole recursion */
+    __shared__ int lds_hit_id[64];
+    if (ids != nullptr) lds_hit_id[lane] = -1;
     int &sp = ou.sp, &mode = ou.mode, &hit_id = ou.hit_id;
     V3 &ret = ou.ret;
     const int depth = lp.depth;
@@ -429,7 +462,12 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             const bool got = tr && h.srf != 0 && !QR_KNOB(4);
             if (tr && !got) { ret = {0, 0, 0}; mode = 1; }
             const int hsi = (int)((h.srf - QR_OFF_SRF) >> 7);          /* surface index: DSurf records are 128 B */
-            if (got && sp == 0) hit_id = (hsi << 1) | h.side;
+            if (ids != nullptr)
+            {
+                int lane_h = (int)(threadIdx.x & 63u);
+                asm volatile("" : "+v"(lane_h));
+                if (got && sp == 0) lds_hit_id[lane_h] = (hsi << 1) | h.side;
+            }
 
             Shaded o;
             shade<COUNT, DIVK, PT>(cx, got, coherent, ray, h, o, cnt, &rng, depth - sp);
@@ -651,7 +689,10 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         cr = cr * 0.5f; cg = cg * 0.5f; cb = cb * 0.5f;
         cr = cr + __shfl_down(cr, 2); cg = cg + __shfl_down(cg, 2); cb = cb + __shfl_down(cb, 2);
     }
-    if (inside && k == 0)
+    /* pixel coordinates and row ownership once more (pixel_of) */
+    int x_e, y_e, k_e;
+    const bool inside_e = pixel_of(ord, fsaa, lp, fr, x_e, y_e, k_e) && k_e == 0;
+    if (inside_e)
     {
         if (fr->fr.ctx_flags & QR_PROP_GAMMA)
         {
@@ -663,8 +704,13 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
         const u32 p = (((u32)cvt_near(cr) & cmask) << 16) |
                       (((u32)cvt_near(cg) & cmask) << 8) |
                        ((u32)cvt_near(cb) & cmask);
-        frame[(size_t)y * frm_w + x] = p;
-        if (ids != nullptr) ids[(size_t)y * frm_w + x] = hit_id;
+        frame[(size_t)y_e * frm_w + x_e] = p;
+        if (ids != nullptr)
+        {
+            int lane_e = (int)(threadIdx.x & 63u);
+            asm volatile("" : "+v"(lane_e));        /* not the address register of the wave's first instructions, kept alive */
+            ids[(size_t)y_e * frm_w + x_e] = lds_hit_id[lane_e];
+        }
     }
 
     if (COUNT)
