@@ -1455,6 +1455,9 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
 #define QR_DDA_BATCH 4      /* solve as soon as this many lanes hold a candidate: an early hit ends the march of every
                              * segment behind it (16: +5 % frame time) */
 #endif
+#ifndef QR_DDA_TWO_REFS
+#define QR_DDA_TWO_REFS 1   /* a step looks at two refs of the current cell when the first is culled (0: one, A/B) */
+#endif
 #ifndef QR_DDA_SPLIT_MAXOWN
 #define QR_DDA_SPLIT_MAXOWN 32
 #endif
@@ -1626,6 +1629,11 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
                         /* ---- next ref of the current cell (or of the up-front members) ---- */
                         const u32 ro = g2.w + rp * 32u;
                         const u32x4 a0 = *(const QR_CONST u32x4 *)(B + ro), a1 = *(const QR_CONST u32x4 *)(B + ro + 16);
+#if QR_DDA_TWO_REFS
+                        /* the ref behind it travels in the same round trip (the array has two refs of slack) and is looked at in
+                         * this step when the first one is culled: the march is a chain of dependent loads, one per step */
+                        const u32x4 c0 = *(const QR_CONST u32x4 *)(B + ro + 32), c1 = *(const QR_CONST u32x4 *)(B + ro + 48);
+#endif
                         rp++;
                         if (a0.y != last0 && a0.y != last1)
                         {
@@ -1634,6 +1642,19 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
                             if (!pool_cull(a0.y, a1, r2, r2 * 1.01f, false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
                             { p_op = a0.x; p_srf = a0.y; p_pos = a0.w; }
                         }
+#if QR_DDA_TWO_REFS
+                        if (p_op == 0 && rp < rend)
+                        {
+                            rp++;
+                            if (c0.y != last0 && c0.y != last1)
+                            {
+                                float b2, m, rhs;
+                                const float r2 = u2f(c0.z);
+                                if (!pool_cull(c0.y, c1, r2, r2 * 1.01f, false, cr, dd, dde, dlen, w.tbd, b2, m, rhs))
+                                { p_op = c0.x; p_srf = c0.y; p_pos = c0.w; }
+                            }
+                        }
+#endif
                     }
                     else
                     {
