@@ -83,8 +83,8 @@ int qr_render0(const void *s_inf, const qr_abi_desc *abi);
  * engines directly (no staging frame, no host copy; strides and index / thnum row ownership are honoured).  It is the
  * caller's promise that the range stays mapped until qr_frame_unregister; qr_render0 itself never retains a pointer it
  * was handed (the engine may free its frame between two calls, engine.cpp:3317-3323).  The binding calls it where the
- * reference allocates the frame and the inverse where it frees it (rt_Scene's constructor / destructor, engine.cpp:2814-
- * 2850 / 3790-3800: INTEGRATION.md).  Frames with a negative stride are served through the staging path.
+ * reference allocates the frame and the inverse where it frees it (rt_Scene's constructor / destructor, engine.cpp:2829-
+ * 2858 / 3815: INTEGRATION.md).  Frames with a negative stride are served through the staging path.
  */
 int qr_frame_register(void *frame, uint64_t bytes);
 int qr_frame_unregister(void *frame);
