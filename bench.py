@@ -291,7 +291,7 @@ def main():
     # launch (qr_render_multi_async): cut into N launches the same work costs 2-2.6x (ramp, drain and tail of
     # every small grid; measured on one GPU, tools/gpu_shard_overhead.py)
     multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(B)] if N > 1 else None
-    state = {"pending": []}
+    state = {"pending": [], "timed": False, "ev": []}
 
     def flush():
         """one grouped exchange for the steps rendered since the last one (fewer, larger collectives)"""
@@ -300,11 +300,18 @@ def main():
             with torch.cuda.stream(comm):
                 for b in state["pending"]:
                     comm.wait_event(ev_render[b])
+                if state["timed"]:
+                    # the exchange itself, on the stream it runs on: from the moment its inputs are rendered to its last copy
+                    x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    x0.record(comm)
                 if args.gather:
                     ex.gather_many([(frames[b], gfinals[b] if gfinals else None) for b in state["pending"]], root=0)
                 else:
                     ex.exchange_many([(frames[b], finals[b]) for b in state["pending"]])
                 ev_comm[grp].record(comm)
+                if state["timed"]:
+                    x1.record(comm)
+                    state["ev"].append((x0, x1, len(state["pending"])))
             state["pending"] = []
 
     def step(i):
@@ -338,9 +345,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    state["timed"] = True
     for i in range(args.steps):
         step(i)
     flush()
+    state["timed"] = False
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
@@ -379,6 +388,13 @@ def main():
         collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": devs,
                       "pattern": ("grouped point-to-point gather of row blocks to rank 0" if args.gather else
                                   "grouped point-to-point all-to-all of row blocks") + ", one call per step group (sharding.py)"}
+        if state["ev"]:
+            # per-step exchange time of THIS rank, HIP events on the communication stream inside the timed region (with the
+            # gloo backend the stream only sees the staging copies; the host part is in ms_per_step)
+            ms = [a.elapsed_time(b) for a, b, _ in state["ev"]]
+            steps_x = sum(n for _, _, n in state["ev"])
+            collective.update(exchange_groups=len(ms), exchange_ms_per_group=sum(ms) / len(ms), exchange_ms_per_step=sum(ms) / max(1, steps_x),
+                              exchange_ms_max_group=max(ms))
 
     # dominant-kernel duration: HIP events recorded on the launch stream around full-frame launches
     scn.set_rows(0, H, 0, 1)

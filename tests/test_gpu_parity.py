@@ -175,6 +175,7 @@ def test_gpu_two_rank_bench_path_on_one_gpu(ranks, mode):
     assert j["n_gpus"] == ranks and j["config"]["frame_check"]["ok"] is True
     assert j["config"]["frame_check"]["timed_frames_match"] is True and j["config"]["assembled_frame_matches"] is True
     assert j["collective"]["ranks"] == ranks and j["collective"]["backend"] == "gloo"
+    assert j["collective"]["exchange_groups"] >= 1 and j["collective"]["exchange_ms_per_step"] >= 0.0
 
 
 def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
