@@ -9,6 +9,8 @@
  *   rt_Node / rt_Array / rt_Surface / rt_Quadric / shape update_fields   object.cpp:813-843, 1761-1825,
  *       2472-2503, 3012-3063, 3120-3910
  *   rt_Light::update_fields object.cpp:649-667, camera vectors of rt_Scene::render engine.cpp:3029-3050, 3256-3260
+ *   rt_Surface::update_minmax / update_bounds, the shapes' adjust_minmax, rt_Node::update_bbgeom,
+ *       rt_Array::update_bounds   object.cpp:849-1091, 1830-2318, 2508-2845, 2957-3956   (qr_hierarchy_bounds)
  *   matrix_from_transform / matrix_mul_matrix / matrix_inverse   core/engine/rtgeom.cpp:59-203
  *   animators: rt_FUNC_ANIM3D of rt_OBJECT, called from rt_Object::update_status (object.cpp:182-190)
  *
@@ -18,9 +20,10 @@
  *
  * Scope (what a frame-to-frame update may change): positions and rotations anywhere in the tree as long as the set
  * of transform nodes ("trnodes": nodes with a non-trivial rotation) and every node's axis mapping and scalers stay
- * the same, and no array with a bounding volume moves -- the engine rebuilds clip boxes, bounding volumes and list
- * structure for those cases (rt_Surface::update_minmax, rt_Array::update_bounds, snode/ssort), this module does not
- * and refuses them with QR_ERR_UNSUP.
+ * the same, and no array with a bounding volume moves -- unless the node tables carry the bounds inputs and
+ * QR_HIER_BOUNDS is given: then clip boxes and bounding volumes are recomputed like the engine does (rt_Surface::
+ * update_minmax, rt_Array::update_bounds) and only a changing SET of transform nodes (list structure: snode / ssort) is
+ * refused with QR_ERR_UNSUP.
  *
  * Plain C ABI; fp32 arithmetic in the reference's operation order: the results are bit-identical to the engine's
  * (tests/test_hierarchy.py, fixtures dumped from the engine by oracle/ref_driver.cpp --tree).
@@ -42,6 +45,7 @@ extern "C" {
 /* the optimisation flags the update depends on, same values as RT_OPTS_* (format.h:43-44) */
 #define QR_OPTS_FSCALE  (1 << 3)
 #define QR_OPTS_TARRAY  (1 << 4)
+#define QR_OPTS_ADJUST  (1 << 7)    /* bounding boxes shrink to what outer clippers leave (rt_Surface::update_minmax) */
 
 /* One object of the hierarchy (rt_OBJECT + what the engine's object keeps of it).  Parents precede children. */
 typedef struct qr_node
@@ -59,8 +63,28 @@ typedef struct qr_node
     int32_t lgt;            /* lights: qr_light index, -1 none                                        */
     int32_t anim;           /* slot of qr_hierarchy_animate's tables, -1 no animator                  */
     float   pov;            /* cameras: distance of the screen plane (rt_Camera::pov)                 */
-    int32_t pad[2];
+    /* inputs of the bounds update (qr_hierarchy_bounds, QR_HIER_BOUNDS); a table without them leaves them 0 / -1 */
+    int32_t bvnode;         /* the array whose bounding volume holds this node (rt_Node::bvnode: the nearest array up the
+                             * tree with RT_REL_BOUND_ARRAY / _INDEX covering it), -1 none                            */
+    int32_t nverts;         /* surfaces: corners of the bounding box the engine allots when the scene description bounds
+                             * the shape (4 plane, 8 quadric; the constructors' conditions, object.cpp:2870-2876, 3096-3101,
+                             * 3190-3196, ...), 0 when it does not                                                   */
+    float   lmin[3], lmax[3];   /* surfaces: the axis clippers of the scene description (rt_SURFACE::min / max, local axes
+                                 * I, J, K; -/+FLT_MAX = none, as RT_INF)                                            */
 } qr_node;
+
+/* What the bounds update computes per node (members of rt_BOUND / rt_SHAPE and of rt_Array's three boxes). */
+typedef struct qr_node_bounds
+{
+    float   bmin[3], bmax[3];   /* surface: bounding box in its sub-world space; array: bvbox (world space)          */
+    float   cmin[3], cmax[3];   /* surface: clipping box (sides that clip, the others at -/+FLT_MAX)                   */
+    float   mid[3], rad;        /* centre and radius of that bounding box's corners (rad = FLT_MAX: unbounded)         */
+    int32_t nverts;             /* corners computed (0: none)                                                          */
+    float   inmin[3], inmax[3], inmid[3], inrad;     /* arrays: inbox (the transform node's space)                    */
+    float   trmin[3], trmax[3], trrad;               /* arrays: trbox                                                   */
+    int32_t inb_form, bvb_form; /* arrays: what the records of the bounding volumes hold -- 0 nothing (left alone),
+                                 * 1 the ellipsoid through the box's corners, 2 (inb only) the sphere around its centre */
+} qr_node_bounds;
 
 /* What the update computes per node (the members of rt_Object it fills). */
 typedef struct qr_node_state
@@ -95,6 +119,18 @@ typedef struct qr_anim_params { int32_t axis; float rate; float period; int32_t 
 void qr_anim_spin(int64_t time, int64_t last_time, float *trm, void *user);
 void qr_anim_swing(int64_t time, int64_t last_time, float *trm, void *user);
 
+/*
+ * Bounding and clipping boxes of every node for the transforms of `nodes` (rt_Surface::update_minmax / update_bounds,
+ * rt_Array::update_bounds, object.cpp:1830-2318, 2534-2845): surfaces from their description's axis clippers, their shape
+ * and -- with QR_OPTS_ADJUST -- the cuts of their outer clippers (read from the snapshot's clipper lists), arrays from their
+ * members.  `blob` is the snapshot the nodes' record indices refer to.
+ */
+int qr_hierarchy_bounds(const void *blob, uint64_t size, const qr_node *nodes, int32_t n, uint32_t opts, qr_node_bounds *out);
+
+#define QR_HIER_BOUNDS      2u  /* qr_hierarchy_apply: the node tables carry the bounds inputs (bvnode, nverts, lmin, lmax):
+                                 * clip boxes of surfaces (min / max / which sides clip) and the records of arrays'
+                                 * bounding volumes are recomputed, so arrays with bounding volumes may move and axis
+                                 * mappings / scalers may change */
 #define QR_HIER_RESET_TILES 1u  /* qr_hierarchy_apply: point every tile at the global list (the camera may have moved;
                                  * QR_UPLOAD_REBIN_TILES bins again on the GPU) */
 

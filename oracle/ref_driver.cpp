@@ -282,11 +282,37 @@ static void dump_node(FILE *f, rt_Object *o, int parent, std::vector<rt_Object *
     }
     else
     {
-        fprintf(f, ", \"srf\": %d", capture_index(0, ((rt_Node *)o)->s_srf));
+        rt_Node *nd = (rt_Node *)o;
+        fprintf(f, ", \"srf\": %d", capture_index(0, nd->s_srf));
+        int bvn = -1;
+        for (size_t i = 0; i < seen.size(); i++) if (seen[i] == nd->bvnode) bvn = (int)i;
+        fprintf(f, ", \"bvnode\": %d", bvn);
+    }
+    if (o->tag >= RT_TAG_PLANE && o->tag < RT_TAG_SURFACE_MAX)
+    {
+        /* bounds (rt_Surface::update_minmax / update_bounds, object.cpp:2690-2845): the inputs -- the axis clippers of the
+         * scene description -- and the engine's results */
+        rt_Surface *sf = (rt_Surface *)o;
+        const rt_SURFACE *sd = (const rt_SURFACE *)o->obj->obj.pobj;
+        fprintf(f, ", "); put_f(f, "lmin", sd->min, 3); fprintf(f, ", "); put_f(f, "lmax", sd->max, 3);
+        fprintf(f, ", "); put_f(f, "bmin", sf->shape->bmin, 3); fprintf(f, ", "); put_f(f, "bmax", sf->shape->bmax, 3);
+        fprintf(f, ", "); put_f(f, "cmin", sf->shape->cmin, 3); fprintf(f, ", "); put_f(f, "cmax", sf->shape->cmax, 3);
+        fprintf(f, ", "); put_f(f, "mid", sf->bvbox->mid, 3); fprintf(f, ", "); put_f(f, "rad", &sf->bvbox->rad, 1);
+        fprintf(f, ", \"verts_num\": %d", (int)sf->bvbox->verts_num);
     }
     if (o->tag == RT_TAG_ARRAY)
     {
         rt_Array *a = (rt_Array *)o;
+        rt_BOUND *bx[3] = { a->inbox, a->bvbox, a->trbox };
+        static const char *bn[3] = { "inbox", "bvbox", "trbox" };
+        for (int b = 0; b < 3; b++)
+        {
+            char key[32];
+            snprintf(key, sizeof(key), "%s_min", bn[b]); fprintf(f, ", "); put_f(f, key, bx[b]->bmin, 3);
+            snprintf(key, sizeof(key), "%s_max", bn[b]); fprintf(f, ", "); put_f(f, key, bx[b]->bmax, 3);
+            snprintf(key, sizeof(key), "%s_mid", bn[b]); fprintf(f, ", "); put_f(f, key, bx[b]->mid, 3);
+            snprintf(key, sizeof(key), "%s_rad", bn[b]); fprintf(f, ", "); put_f(f, key, &bx[b]->rad, 1);
+        }
         fprintf(f, ", \"inb\": %d, \"bvb\": %d}", capture_index(0, a->s_inb), capture_index(0, a->s_bvb));
         for (int i = 0; i < a->obj_num; i++) dump_node(f, a->obj_arr[i], me, seen, first);
     }
@@ -318,6 +344,7 @@ static bool dump_tree(rt_Scene *sc, const char *scene, long time_ms, const char 
  * update meets combinations the stock scenes do not have (fixtures tests/golden/tree/fuzz_*; the frame is not kept).
  */
 static uint64_t g_jit = 0;
+static int g_shift_only = 0;        /* --shift SEED: positions only (nothing else of a transform changes: a scene "a moment later") */
 static uint32_t jit_next() { g_jit ^= g_jit << 13; g_jit ^= g_jit >> 7; g_jit ^= g_jit << 17; return (uint32_t)(g_jit >> 11); }
 static void jitter_tree(rt_OBJECT *arr, int n, int level)
 {
@@ -327,6 +354,14 @@ static void jitter_tree(rt_OBJECT *arr, int n, int level)
     {
         rt_OBJECT *o = &arr[i];
         const bool cam = o->obj.tag == RT_TAG_CAMERA;
+        if (g_shift_only)
+        {
+            /* two thirds of the objects move by up to +-0.5 along every axis; the camera stays */
+            if (!cam && jit_next() % 3 != 0)
+                for (int a = 0; a < 3; a++) o->trm.pos[a] += (rt_real)((int)(jit_next() % 101) - 50) / 100.0f;
+            if (o->obj.tag == RT_TAG_ARRAY && level < 16) jitter_tree((rt_OBJECT *)o->obj.pobj, o->obj.obj_num, level + 1);
+            continue;
+        }
         const uint32_t mode = jit_next() % 10;
         for (int a = 0; a < 3 && !cam; a++)
         {
@@ -460,6 +495,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--tree") && i + 1 < argc) tree_path = argv[++i];
         else if (!strcmp(argv[i], "--shim")) { n_simd = 1; s_type = 8; k_size = 1; }
         else if (!strcmp(argv[i], "--swarm") && i + 1 < argc) sscanf(argv[++i], "%d,%ld,%d", &swarm_n, &swarm_seed, &swarm_mix);
+        else if (!strcmp(argv[i], "--shift") && i + 1 < argc) { g_jit = 0xC2B2AE3D27D4EB4Full * (uint64_t)(atol(argv[++i]) + 1); g_shift_only = 1; }
         else if (!strcmp(argv[i], "--jitter") && i + 1 < argc) g_jit = 0x9E3779B97F4A7C15ull * (uint64_t)(atol(argv[++i]) + 1);   /* every frame through ref_shim.cpp -> qr_render0 */
         else { usage(); return 2; }
     }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "qr_frame_register", "qr_frame_unregister",
     "qr_frame_hash", "qr_last_error", "qr_version", "qr_device_count", "qr_kernel_name", "qr_capture_index",
     # include/qr_hierarchy.h
-    "qr_hierarchy_update", "qr_hierarchy_animate", "qr_hierarchy_apply", "qr_anim_spin", "qr_anim_swing",
+    "qr_hierarchy_update", "qr_hierarchy_animate", "qr_hierarchy_apply", "qr_hierarchy_bounds", "qr_anim_spin", "qr_anim_swing",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
     L.qr_frame_unregister.argtypes = [vp]
     L.qr_render_timed.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.qr_hierarchy_update.argtypes = [vp, ci, ctypes.c_uint32, vp]
+    L.qr_hierarchy_bounds.argtypes = [vp, cu64, vp, ci, ctypes.c_uint32, vp]
     L.qr_hierarchy_animate.argtypes = [vp, ci, ctypes.c_int64, vp, vp, vp, ci]
     L.qr_hierarchy_apply.argtypes = [vp, cu64, vp, vp, ci, ctypes.c_uint32, ci, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(cu64)]
     _lib = L
@@ -158,7 +159,14 @@ def node_dtype():
     import numpy as np
     return np.dtype([("parent", "<i4"), ("tag", "<i4"), ("scl", "<f4", 3), ("rot", "<f4", 3), ("pos", "<f4", 3),
                      ("shape", "<f4", 3), ("srf", "<i4"), ("inb", "<i4"), ("bvb", "<i4"), ("lgt", "<i4"), ("anim", "<i4"),
-                     ("pov", "<f4"), ("pad", "<i4", 2)])
+                     ("pov", "<f4"), ("bvnode", "<i4"), ("nverts", "<i4"), ("lmin", "<f4", 3), ("lmax", "<f4", 3)])
+
+
+def node_bounds_dtype():
+    import numpy as np
+    return np.dtype([("bmin", "<f4", 3), ("bmax", "<f4", 3), ("cmin", "<f4", 3), ("cmax", "<f4", 3), ("mid", "<f4", 3), ("rad", "<f4"),
+                     ("nverts", "<i4"), ("inmin", "<f4", 3), ("inmax", "<f4", 3), ("inmid", "<f4", 3), ("inrad", "<f4"),
+                     ("trmin", "<f4", 3), ("trmax", "<f4", 3), ("trrad", "<f4"), ("inb_form", "<i4"), ("bvb_form", "<i4")])
 
 
 def node_state_dtype():
@@ -168,6 +176,7 @@ def node_state_dtype():
 
 
 HIER_RESET_TILES = 1
+HIER_BOUNDS = 2
 ANIM_SPIN, ANIM_SWING = "spin", "swing"
 
 
@@ -177,6 +186,16 @@ def hierarchy_update(nodes, opts):
     nodes = np.ascontiguousarray(nodes, dtype=node_dtype())
     out = np.zeros(len(nodes), dtype=node_state_dtype())
     _check(lib().qr_hierarchy_update(nodes.ctypes.data_as(ctypes.c_void_p), len(nodes), opts, out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def hierarchy_bounds(blob, nodes, opts):
+    """Bounding and clipping boxes of every node (qr_hierarchy_bounds): node_bounds_dtype array."""
+    import numpy as np
+    nodes = np.ascontiguousarray(nodes, dtype=node_dtype())
+    out = np.zeros(len(nodes), dtype=node_bounds_dtype())
+    buf = ctypes.create_string_buffer(blob, len(blob))
+    _check(lib().qr_hierarchy_bounds(buf, len(blob), nodes.ctypes.data_as(ctypes.c_void_p), len(nodes), opts, out.ctypes.data_as(ctypes.c_void_p)))
     return out
 
 

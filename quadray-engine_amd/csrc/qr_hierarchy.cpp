@@ -9,7 +9,9 @@
 #include "qr_internal.h"
 #include "qr_hierarchy.h"
 
+#include <cfloat>
 #include <cmath>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -336,16 +338,16 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
             const bool has_record = (is_surface(next[i].tag) || next[i].tag == QR_NODE_ARRAY) && next[i].srf >= 0;
             if (has_record && (a.trnode != b.trnode || a.obj_has_trm != b.obj_has_trm))
                 return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
-            if (has_record &&
+            if (has_record && !(flags & QR_HIER_BOUNDS) &&
                 (!same_bits(a.map, b.map, sizeof(a.map)) || !same_bits(a.sgn, b.sgn, sizeof(a.sgn)) || !same_bits(a.scl, b.scl, sizeof(a.scl))))
-                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": axis mapping or scalers change (clip boxes would)");
+                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": axis mapping or scalers change (clip boxes would; QR_HIER_BOUNDS recomputes them)");
             moved[(size_t)i] = !same_bits(a.mtx, b.mtx, sizeof(a.mtx));
         }
         for (int i = n - 1; i >= 0; i--)
         {
             if (moved[(size_t)i] && next[i].parent >= 0) moved[(size_t)next[i].parent] = 1;  /* children come later: one sweep */
-            if (next[i].tag == QR_NODE_ARRAY && moved[(size_t)i] && (next[i].inb >= 0 || next[i].bvb >= 0))
-                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": an array with a bounding volume moves");
+            if (next[i].tag == QR_NODE_ARRAY && moved[(size_t)i] && (next[i].inb >= 0 || next[i].bvb >= 0) && !(flags & QR_HIER_BOUNDS))
+                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": an array with a bounding volume moves (QR_HIER_BOUNDS recomputes the volumes)");
         }
     }
 
@@ -378,6 +380,55 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         {
             /* rt_Light::update_fields 649-667 */
             L[nd.lgt].pos[0] = m[3][0]; L[nd.lgt].pos[1] = m[3][1]; L[nd.lgt].pos[2] = m[3][2];
+        }
+    }
+    if (flags & QR_HIER_BOUNDS)
+    {
+        /* clip boxes of surfaces and the records of arrays' bounding volumes for the new transforms (qr_hbounds.cpp) */
+        std::vector<qr_node_bounds> nb((size_t)n);
+        rc = qr_hierarchy_bounds(blob, size, next, n, opts, nb.data());
+        if (rc != QR_OK) return rc;
+        for (int i = 0; i < n; i++)
+        {
+            const qr_node &nd = next[i];
+            const qr_node_state &s = st[(size_t)i];
+            const qr_node_bounds &b = nb[(size_t)i];
+            if (is_surface(nd.tag) && nd.srf >= 0)
+            {
+                /* rt_Surface::update_bounds 2824-2844: which sides clip, and the box relative to the position */
+                qr_surface &r = S[nd.srf];
+                uint32_t mt = 0;
+                for (int x = 0; x < 3; x++)
+                {
+                    const float pp = s.trnode == i ? 0.0f : s.mtx[12 + x];
+                    if (b.cmin[x] != -FLT_MAX) mt |= 1u << x;
+                    if (b.cmax[x] != +FLT_MAX) mt |= 1u << (3 + x);
+                    r.min[x] = b.bmin[x] - pp;
+                    r.max[x] = b.bmax[x] - pp;
+                }
+                r.minmax_t = mt;
+            }
+            if (nd.tag != QR_NODE_ARRAY) continue;
+            /* rt_Array::update_bounds 2181-2310: the records of the inner and outer bounding volume */
+            auto ellipsoid = [&](qr_surface &r, const float *lo, const float *hi) {
+                for (int x = 0; x < 3; x++) r.pos[x] = (lo[x] + hi[x]) * 0.5f;
+                r.sci[3] = 0.75f;                                       /* the unit cube's radius squared */
+                for (int x = 0; x < 3; x++) { const float d = hi[x] - lo[x]; r.sci[x] = 1.0f / (d * d); }
+            };
+            if (nd.inb >= 0 && b.inb_form == 1)
+            {
+                ellipsoid(S[nd.inb], b.inmin, b.inmax);
+                put_mapping(S[nd.inb], s, next);                        /* rt_Array::update_fields 1790-1802: the array's own mapping */
+            }
+            if (nd.inb >= 0 && b.inb_form == 2)
+            {
+                qr_surface &r = S[nd.inb];
+                r.axes = 0u | 1u << 2 | 2u << 4;                         /* identity axis map, no signs; no transform node of its own */
+                r.has_trm = 0; r.shift = 0; r.trnode = QR_NULL;
+                for (int x = 0; x < 3; x++) { r.pos[x] = b.inmid[x]; r.sci[x] = 1.0f; }
+                r.sci[3] = b.inrad * b.inrad;
+            }
+            if (nd.bvb >= 0 && b.bvb_form == 1) ellipsoid(S[nd.bvb], b.bmin, b.bmax);
         }
     }
     if (camera >= 0)

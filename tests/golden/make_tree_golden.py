@@ -36,6 +36,15 @@ FUZZ = [("test14", 1, []), ("test14", 2, []), ("test14", 3, ["--opts", "none"]),
         ("demo03", 0, ["--swarm", "96,5,1"]), ("test09", 7, ["--swarm", "60,6,1"])]
 
 
+# scenes "a moment later" (oracle/ref_driver.cpp --shift SEED: two thirds of the objects moved by up to 0.5 along every axis,
+# nothing else of a transform changed): pairs (A, B) of the same scene.  Kept per state: tree, snapshot (texels zeroed) and, for
+# B, the reference's frame.  Tests patch A's snapshot with B's transforms (qr_hierarchy_apply + QR_HIER_BOUNDS): every record
+# field must equal B's snapshot, and the frame rendered from the patched snapshot B's frame.  Arrays with bounding volumes
+# move in all of them (obj_frametable.h:22,133, obj_aliencube.h:215, scn_demo03.h:171,177, the swarm's groups).
+MOVED = [("demo02", [], 1, 2), ("demo03", [], 3, 4), ("demo01", [], 5, 6), ("test14", [], 3, 4), ("test16", [], 3, 4),
+         ("demo03", ["--swarm", "96,5,1"], 7, 8)]
+
+
 def run(scene, w, h, args, tmp):
     raw, qrs, tree = (os.path.join(tmp, n) for n in ("f.raw", "s.qrs", "t.json"))
     cmd = [REF, "--scene", scene, "-w", str(w), "-h", str(h), "--out", raw, "--snapshot", qrs, "--tree", tree] + args
@@ -87,9 +96,37 @@ def fuzz():
         print(name)
 
 
+def moved():
+    import struct
+    for scene, args, sa, sb in MOVED:
+        for seed, keep_frame in ((sa, False), (sb, True)):
+            tmp = tempfile.mkdtemp(prefix="qrtree_")
+            frame, blob, tree = run(scene, 64, 48, ["--shift", str(seed)] + args, tmp)
+            b = bytearray(blob)
+            n_texels, off_texels = struct.unpack_from("<I", b, 4 * 9)[0], struct.unpack_from("<I", b, 4 * 16)[0]
+            name = "moved_%s%s_s%d" % (scene, "_swarm" if args else "", seed)
+            if keep_frame:
+                bio = io.BytesIO(); np.save(bio, frame.astype("<u4"))
+                with open(os.path.join(OUT, name + ".frame.npy.gz"), "wb") as f:
+                    f.write(gzip.compress(bio.getvalue(), 9, mtime=0))
+            else:
+                # A keeps its texels: the patched snapshot is rendered (textures do not move)
+                pass
+            if keep_frame:
+                b[off_texels:off_texels + 4 * n_texels] = bytes(4 * n_texels)
+            with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
+                f.write(gzip.compress(tree, 9, mtime=0))
+            with open(os.path.join(OUT, name + ".qrs.gz"), "wb") as f:
+                f.write(gzip.compress(bytes(b), 9, mtime=0))
+            print(name)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["fuzz"]:
         fuzz()
+    elif sys.argv[1:] == ["moved"]:
+        moved()
     else:
         main()
         fuzz()
+        moved()

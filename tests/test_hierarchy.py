@@ -18,6 +18,11 @@ TREE = os.path.join(GOLDEN, "tree")
 CASES = sorted(n[:-8] for n in os.listdir(TREE) if n.endswith(".json.gz") and n[:-8] in MANIFEST)
 # transforms fuzzed inside the reference engine (ref_driver --jitter): tree + that run's snapshot (texels zeroed)
 FUZZ = sorted(n[:-8] for n in os.listdir(TREE) if n.startswith("fuzz_") and n.endswith(".json.gz"))
+# pairs of one scene "a moment later" (ref_driver --shift A / B: two thirds of the objects moved, arrays with bounding volumes
+# among them): (state the snapshot is patched from, state it is patched to -- tree, the engine's snapshot and frame)
+MOVED = [("moved_demo02_s1", "moved_demo02_s2"), ("moved_demo03_s3", "moved_demo03_s4"), ("moved_demo01_s5", "moved_demo01_s6"),
+         ("moved_test14_s3", "moved_test14_s4"), ("moved_test16_s3", "moved_test16_s4"), ("moved_demo03_swarm_s7", "moved_demo03_swarm_s8")]
+MOVED_ALL = sorted(set(n for p in MOVED for n in p))
 
 # (snapshot + tree the scene is patched from, tree of the target time, where the reference's frame of that time is)
 ANIMATED = [
@@ -42,6 +47,9 @@ def load_tree(qr, name):
         r["scl"], r["rot"], r["pos"], r["shape"] = _f32(n["scl"]), _f32(n["rot"]), _f32(n["pos"]), _f32(n["shape"])
         r["srf"], r["inb"], r["bvb"], r["lgt"] = n.get("srf", -1), n.get("inb", -1), n.get("bvb", -1), n.get("lgt", -1)
         r["anim"] = -1
+        r["bvnode"], r["nverts"] = n.get("bvnode", -1), n.get("verts_num", 0)
+        if "lmin" in n:
+            r["lmin"], r["lmax"] = _f32(n["lmin"]), _f32(n["lmax"])
         if "pov" in n:
             r["pov"] = _f32(n["pov"])[0]
     return t, nodes
@@ -76,6 +84,97 @@ def test_update_and_fields_match_the_engine(qr, name):
     blob = _fuzz_blob(name) if name in FUZZ else load_blob(name)
     assert qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"]) == blob
     assert qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"], base=nodes) == blob
+    # with the bounds update on top (clip boxes of every surface, records of the arrays' bounding volumes): still nothing
+    assert qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"], base=nodes, flags=qr.HIER_BOUNDS) == blob
+
+
+@pytest.mark.parametrize("name", CASES + FUZZ + MOVED_ALL)
+def test_bounds_match_the_engine(qr, name):
+    """Bounding and clipping boxes (qr_hierarchy_bounds: rt_Surface::update_minmax / update_bounds, rt_Array::update_bounds,
+    object.cpp:1830-2318, 2534-2845), bit for bit: every surface's bounding box, clipping box, centre and radius of the
+    box's corners; every array's inbox, bvbox and trbox with their radii."""
+    t, nodes = load_tree(qr, name)
+    blob = _fuzz_blob(name) if (name in FUZZ or name in MOVED_ALL) else load_blob(name)
+    b = qr.hierarchy_bounds(blob, nodes, t["opts"])
+    n_srf = n_arr = 0
+    for i, n in enumerate(t["nodes"]):
+        if "bmin" in n:
+            n_srf += 1
+            for k in ("bmin", "bmax", "cmin", "cmax"):
+                assert (bits(b[i][k]) == bits(_f32(n[k]))).all(), (i, n["tag"], k)
+            assert b[i]["nverts"] == n["verts_num"]
+            if n["verts_num"]:
+                assert (bits(b[i]["mid"]) == bits(_f32(n["mid"]))).all() and bits(b[i]["rad"]) == bits(_f32(n["rad"]))[0], i
+        if "inbox_min" in n:
+            n_arr += 1
+            for k, key in (("inmin", "inbox_min"), ("inmax", "inbox_max"), ("bmin", "bvbox_min"), ("bmax", "bvbox_max"),
+                           ("trmin", "trbox_min"), ("trmax", "trbox_max")):
+                assert (bits(b[i][k]) == bits(_f32(n[key]))).all(), (i, k)
+            for k, key in (("inrad", "inbox_rad"), ("rad", "bvbox_rad"), ("trrad", "trbox_rad")):
+                assert bits(b[i][k]) == bits(_f32(n[key]))[0], (i, k)
+    assert n_srf > 0 and n_arr > 0
+
+
+# words of a qr_surface record the hierarchy owns (include/qr_scene.h): everything but list heads (clip 38, lst 44-47),
+# the transform node's and the materials' indices (39-41: numbered per snapshot) and padding
+_OWNED = [w for w in range(44) if w not in (38, 39, 40, 41)]
+
+
+def _records(blob):
+    import struct
+    h = struct.unpack_from("<26I", blob, 0)
+    return np.frombuffer(blob, dtype=np.uint32, count=h[4] * 64, offset=h[11]).reshape(h[4], 64)
+
+
+def _moved_patch(qr, a, b, flags):
+    ta, na = load_tree(qr, a)
+    tb, nb = load_tree(qr, b)
+    assert len(na) == len(nb) and (na["parent"] == nb["parent"]).all() and (na["tag"] == nb["tag"]).all()
+    nxt = nb.copy()
+    for k in ("srf", "inb", "bvb", "lgt"):
+        nxt[k] = na[k]                      # the records of the snapshot that is patched
+    return ta, na, tb, nb, qr.hierarchy_apply(_fuzz_blob(a), nxt, tb["opts"], camera=tb["camera"], base=na, flags=flags)
+
+
+@pytest.mark.parametrize("a,b", MOVED)
+def test_moved_bounding_volumes_give_the_engines_records(qr, a, b):
+    """Arrays with bounding volumes move: without QR_HIER_BOUNDS the update is refused; with it EVERY field of every
+    surface, array and bounding-volume record of the patched snapshot equals the engine's own snapshot of the target state
+    (positions, clip boxes and which sides clip, quadric coefficients, maps; the volumes' centres and coefficients)."""
+    with pytest.raises(qr.QrError, match="bounding volume"):
+        _moved_patch(qr, a, b, 0)
+    ta, na, tb, nb, out = _moved_patch(qr, a, b, qr.HIER_BOUNDS)
+    got, want = _records(out), _records(_fuzz_blob(b))
+    n = 0
+    for i in range(len(na)):
+        for k in ("srf", "inb", "bvb"):
+            ia, ib = int(na[i][k]), int(nb[i][k])
+            if ia < 0 or ib < 0:
+                assert ia < 0 and ib < 0
+                continue
+            assert (got[ia, _OWNED] == want[ib, _OWNED]).all(), (i, k, [w for w in _OWNED if got[ia, w] != want[ib, w]])
+            n += 1
+    assert n > 10
+    moved_volumes = sum(1 for i in range(len(na)) if na[i]["tag"] == -1 and na[i]["inb"] >= 0
+                        and (got[int(na[i]["inb"])] != _records(_fuzz_blob(a))[int(na[i]["inb"])]).any())
+    assert moved_volumes > 0, "no bounding volume changed: the pair does not test anything"
+
+
+@pytest.mark.parametrize("a,b", MOVED)
+def test_moved_scene_renders_to_the_reference_frame(qr, oracle, a, b):
+    """... and end to end: patched snapshot -> rebuilt lists -> the oracle renders the reference's frame of the target state."""
+    _, _, _, _, out = _moved_patch(qr, a, b, qr.HIER_BOUNDS | qr.HIER_RESET_TILES)
+    frame, _, _ = oracle.render(qr.build_lists(out), threads=8)
+    assert (frame == (tree_frame(b) & 0xFFFFFF)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a,b", MOVED)
+def test_gpu_moved_scene_renders_to_the_reference_frame(qr, a, b):
+    _, _, _, _, out = _moved_patch(qr, a, b, qr.HIER_BOUNDS | qr.HIER_RESET_TILES)
+    sc = qr.Scene(qr.build_lists(out), rebin_tiles=True)
+    frame = sc.render().cpu().numpy().view(np.uint32) & 0xFFFFFF
+    assert (frame == (tree_frame(b) & 0xFFFFFF)).all()
 
 
 def _animators(t):
