@@ -1120,6 +1120,12 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
             std::vector<uint32_t> &hv_ent = out.order, lt_ent;
             hv_ent.clear();
             hv_ent.reserve(n_sched * 2); lt_ent.reserve(n_sched * 2);
+            /* footprints over an empty tile only have zeros to store: runs of them along a row share ONE wave (schedule head
+             * = run length, 1..QR_CLEAR_RUN_MAX: values below 256 are no list offsets).  Half of demo scene 1's 32 400
+             * footprints at 1080p are such; QR_CLEAR_RUN=1 gives every one its own wave again */
+            static const int clear_run = []() { const char *e = getenv("QR_CLEAR_RUN"); const int r = e ? atoi(e) : QR_CLEAR_RUN_MAX;
+                                                return r < 1 ? 1 : (r > QR_CLEAR_RUN_MAX ? QR_CLEAR_RUN_MAX : r); }();
+            std::vector<uint8_t> empty((size_t)nbx * nby, 0);
             for (int ty = 0; ty * gy < nby; ty++)
                 for (int tx = 0; tx * gx < nbx; tx++)
                 {
@@ -1145,15 +1151,27 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
                                 if (tlx == x1 / frm.tile_w && tly == y1 / frm.tile_h) head = tile_off[(size_t)tly * frm.tls_row + tlx];
                                 else for (int yy = tly; yy <= y1 / frm.tile_h; yy++) for (int xx = tlx; xx <= x1 / frm.tile_w; xx++) hv |= tile_heavy[(size_t)yy * frm.tls_row + xx];
                             }
+                            if (head == 0) { empty[(size_t)by * nbx + bx] = 1; continue; }
                             const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14) | ((uint32_t)(hv & 3) << 30);
                             std::vector<uint32_t> &dst = hv ? hv_ent : lt_ent;
                             dst.push_back(ent); dst.push_back(head);
                         }
                 }
             hv_ent.insert(hv_ent.end(), lt_ent.begin(), lt_ent.end());
+            for (int by = 0; by < nby; by++)
+                for (int bx = 0; bx < nbx; )
+                {
+                    if (!empty[(size_t)by * nbx + bx]) { bx++; continue; }
+                    int run = 1;
+                    while (run < clear_run && bx + run < nbx && empty[(size_t)by * nbx + bx + run]) run++;
+                    hv_ent.push_back((uint32_t)bx | ((uint32_t)by << 14));
+                    hv_ent.push_back((uint32_t)run);
+                    bx += run;
+                }
         }
         tick("schedule");
-        if (out.order.size() != n_sched * 2) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
+        if (out.order.size() > n_sched * 2 || (out.order.size() & 1)) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
+        const size_t n_waves = out.order.size() / 2;        /* schedule entries: one per wave (fewer than footprints: clear runs) */
         out.block_first.clear(); out.block_row.clear();
         if (sched_blocks > 1)
         {
@@ -1187,9 +1205,9 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
 
         DevHeader &h = *b.at<DevHeader>(0);
         h.fr = frm;
-        h.off_shade = b.o_shd; h.off_tiles = o_til; h.off_order = o_ord; h.n_blocks = (uint32_t)n_sched;
+        h.off_shade = b.o_shd; h.off_tiles = o_til; h.off_order = o_ord; h.n_blocks = (uint32_t)n_waves;
         b.alloc(64, 64);                    /* tail padding: wide scalar loads of the last record stay inside */
-        out.off_order = o_ord; out.n_sched = (uint32_t)n_sched;
+        out.off_order = o_ord; out.n_sched = (uint32_t)n_waves;
         out.off_srf = b.o_srf; out.off_shade = b.o_shd; out.off_mat = b.o_mat; out.off_lgt = b.o_lgt; out.off_tex = b.o_tex; out.off_tiles = o_til;
         out.n_srf = (uint32_t)n_srf; out.n_mat = (uint32_t)n_mat; out.n_lgt = (uint32_t)n_lgt; out.n_tex = (uint32_t)n_tex; out.n_tiles = (uint32_t)T.size();
         out.off_lists = o_ord + (uint32_t)(n_sched * 8 + 16);
@@ -1309,7 +1327,12 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     {
         const uint32_t e = ord[2 * i], hd = ord[2 * i + 1];
         if ((int)(e & 0x3FFFu) * fw >= p.frm.frm_w || (int)((e >> 14) & 0x3FFFu) * fh >= p.frm.frm_h) return bad("schedule footprint outside the frame");
-        if (hd != QR_SCHED_PER_LANE) if (const char *m = check_list(hd)) return bad(m);
+        if (hd < 256u)
+        {
+            /* a run of hd empty footprints along the row (0: one) */
+            if (hd > QR_CLEAR_RUN_MAX || ((int)(e & 0x3FFFu) + (int)(hd ? hd : 1u) - 1) * fw >= p.frm.frm_w) return bad("clear run leaves the frame");
+        }
+        else if (hd != QR_SCHED_PER_LANE) if (const char *m = check_list(hd)) return bad(m);
     }
     for (uint32_t i = 0; i <= p.n_srf; i++)
     {

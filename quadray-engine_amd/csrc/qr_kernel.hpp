@@ -298,22 +298,26 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     if (lp.group_stride != 1 && (group - lp.group_first) % lp.group_stride != 0) inside = false;
     if (inside && lp.thnum > 1) inside = (y % lp.thnum) == lp.index;
     if (!any_lane(inside)) return;                 /* whole wave outside this launch's rows */
-    if (sched_head == 0)
+    if (sched_head < 256u)
     {
-        /* empty tile: no ray of the footprint meets anything; the reference's pipeline ends with
-         * colour 0 for such a packet (clamp, sqrt and cvt of 0 are 0), so store it and leave */
+        /* empty tiles: no ray of these footprints meets anything; the reference's pipeline ends with colour 0 for such a
+         * packet (clamp, sqrt and cvt of 0 are 0), so store it and leave.  The head is the number of footprints of the
+         * run along the row (qr_compile.cpp; 0: one) */
+        const u32 run = sched_head == 0 ? 1u : sched_head;
+        unsigned long long n = 0;
+        for (u32 i = 0; i < run; i++)
         {
             int x0, y0, k0;
-            const bool in0 = pixel_of(ord, fsaa, lp, fr, x0, y0, k0);
+            const bool in0 = pixel_of(ord + i, fsaa, lp, fr, x0, y0, k0);
             if (in0 && k0 == 0)
             {
                 frame[(size_t)y0 * frm_w + x0] = 0u;
                 if (ids != nullptr) ids[(size_t)y0 * frm_w + x0] = -1;
             }
+            if (COUNT && in0) n++;
         }
         if (COUNT)
         {
-            unsigned long long n = inside ? 1ull : 0ull;
             for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
             if (lane == 0 && n != 0) atomicAdd(&counters[0], n);
         }

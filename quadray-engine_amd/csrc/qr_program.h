@@ -86,6 +86,7 @@ struct CBvExt
 #define QR_LISTF_GRID  8u       /* only in CLight::shadow: the offset is that of a CGrid, the shadow list depends on where the
                                  * surface was hit                                                                        */
 #define QR_LIST_OFF(x) ((x) & ~31u)
+#define QR_CLEAR_RUN_MAX 16     /* a schedule head below 256 is a run of that many footprints over empty tiles (0: one) */
 #define QR_LONG_CELLS  192      /* a list needs this many cells (and four bounding volumes) to be flagged QR_LISTF_LONG */
 
 /*
