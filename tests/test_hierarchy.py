@@ -115,6 +115,24 @@ def test_bounds_match_the_engine(qr, name):
     assert n_srf > 0 and n_arr > 0
 
 
+def test_bounds_reject_a_broken_node_table(qr):
+    """record indices outside the snapshot, a bounding-volume node that is no array in front of the node: refused, not read"""
+    t, nodes = load_tree(qr, "demo02_160")
+    blob = load_blob("demo02_160")
+    srf = [i for i, n in enumerate(t["nodes"]) if "bmin" in n]
+    bad = nodes.copy(); bad[srf[0]]["srf"] = 1 << 20
+    with pytest.raises(qr.QrError):
+        qr.hierarchy_bounds(blob, bad, t["opts"])
+    bad = nodes.copy(); bad[srf[0]]["bvnode"] = len(nodes) - 1
+    with pytest.raises(qr.QrError):
+        qr.hierarchy_bounds(blob, bad, t["opts"])
+    bad = nodes.copy(); bad[srf[3]]["bvnode"] = srf[0]                  # a surface, not an array
+    with pytest.raises(qr.QrError):
+        qr.hierarchy_bounds(blob, bad, t["opts"])
+    with pytest.raises(qr.QrError):
+        qr.hierarchy_bounds(blob[:4096], nodes, t["opts"])              # truncated snapshot
+
+
 # words of a qr_surface record the hierarchy owns (include/qr_scene.h): everything but list heads (clip 38, lst 44-47),
 # the transform node's and the materials' indices (39-41: numbered per snapshot) and padding
 _OWNED = [w for w in range(44) if w not in (38, 39, 40, 41)]
