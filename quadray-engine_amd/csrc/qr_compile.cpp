@@ -367,11 +367,36 @@ struct Builder
     uint32_t srf_off(int si) const { return o_srf + (uint32_t)si * (uint32_t)sizeof(DSurf); }
 
     /* ---- surface lists ---- */
-    /* chains compiled so far by content (see compile_list) */
-    struct DedupEnt { size_t first, len; uint32_t off; uint8_t heavy; };
-    std::unordered_multimap<uint64_t, DedupEnt> dedup_map;
+    /* chains compiled so far by content (see compile_list): an open hash of entry indices, entries chained on collisions */
+    struct DedupEnt { size_t first, len; uint64_t key; uint32_t off; uint8_t heavy; int32_t next; };
+    std::vector<DedupEnt> dedup_ent;
+    std::vector<int32_t> dedup_slot = std::vector<int32_t>(1024, -1);
     std::vector<int32_t> dedup_pool, dk;
+    int32_t dedup_last = -1;                /* the entry the previous chain matched or made: neighbouring tiles repeat it */
     bool dedup_on = !(getenv("QR_LIST_DEDUP") && atoi(getenv("QR_LIST_DEDUP")) == 0);      /* QR_LIST_DEDUP=0: one program per chain (A/B) */
+
+    bool dedup_equal(const DedupEnt &d, uint64_t key) const
+    {
+        return d.key == key && d.len == dk.size() && memcmp(dedup_pool.data() + d.first, dk.data(), dk.size() * sizeof(int32_t)) == 0;
+    }
+    void dedup_add(uint64_t key, uint32_t off, uint8_t heavy)
+    {
+        if ((dedup_ent.size() + 1) * 2 > dedup_slot.size())
+        {
+            dedup_slot.assign(dedup_slot.size() * 4, -1);
+            for (size_t i = 0; i < dedup_ent.size(); i++)
+            {
+                int32_t &sl = dedup_slot[(size_t)(dedup_ent[i].key >> 20) & (dedup_slot.size() - 1)];
+                dedup_ent[i].next = sl; sl = (int32_t)i;
+            }
+        }
+        int32_t &sl = dedup_slot[(size_t)(key >> 20) & (dedup_slot.size() - 1)];
+        dedup_ent.push_back(DedupEnt{ dedup_pool.size(), dk.size(), key, off, heavy, sl });
+        sl = dedup_last = (int32_t)dedup_ent.size() - 1;
+        dedup_pool.insert(dedup_pool.end(), dk.begin(), dk.end());
+    }
+
+    struct Restart {};                      /* thrown by compile_list: a long chain in a build that assumed there is none */
 
     uint32_t compile_list(int head)
     {
@@ -384,14 +409,14 @@ struct Builder
             chain_pos.resize(n1, 0); chain_stamp.resize(n1, -1);
         }
         if (list_off[head]) return list_off[head];
-        ch.clear();
         stamp++;
+        int n = 0;
         for (int e = head; e != QR_NULL; e = E[e].next)
         {
-            chain_stamp[e] = stamp; chain_pos[e] = (int)ch.size();
-            ch.push_back(Tmp{e, 0, E[e].simd, QR_NULL, true});
+            if ((size_t)n >= E.size()) throw Fail{QR_ERR_ARG, "cyclic list"};
+            chain_stamp[e] = stamp; chain_pos[e] = n++;
         }
-        const int n = (int)ch.size();
+        if (box_ok && n >= QR_LONG_CELLS) throw Restart{};
         /* The engine hands every screen tile a chain of its own, and most neighbours hold the same surfaces in the same order:
          * a chain whose elements (surface, kind, position of the array's last member) equal those of a chain compiled
          * before IS that program -- the cells depend on nothing else.  One copy: a third of the compile time at 1080p, and
@@ -399,9 +424,9 @@ struct Builder
         uint64_t dkey = 1469598103934665603ull;
         bool dedup = dedup_on;
         dk.clear();
-        for (int i = 0; i < n && dedup; i++)
+        for (int e = head; e != QR_NULL && dedup; e = E[e].next)
         {
-            const qr_elem &el = E[ch[i].e];
+            const qr_elem &el = E[e];
             int rel = -1;
             if (el.data != QR_NULL)
             {
@@ -413,17 +438,21 @@ struct Builder
         }
         if (dedup)
         {
-            auto range = dedup_map.equal_range(dkey);
-            for (auto it = range.first; it != range.second; ++it)
+            int32_t hit = -1;
+            if (dedup_last >= 0 && dedup_equal(dedup_ent[(size_t)dedup_last], dkey)) hit = dedup_last;
+            else
+                for (int32_t i = dedup_slot[(size_t)(dkey >> 20) & (dedup_slot.size() - 1)]; i >= 0; i = dedup_ent[(size_t)i].next)
+                    if (dedup_equal(dedup_ent[(size_t)i], dkey)) { hit = i; break; }
+            if (hit >= 0)
             {
-                const DedupEnt &d = it->second;
-                if (d.len == dk.size() && memcmp(dedup_pool.data() + d.first, dk.data(), dk.size() * sizeof(int32_t)) == 0)
-                {
-                    list_off[head] = d.off; list_heavy[head] = d.heavy;
-                    return d.off;
-                }
+                const DedupEnt &d = dedup_ent[(size_t)hit];
+                dedup_last = hit;
+                list_off[head] = d.off; list_heavy[head] = d.heavy;
+                return d.off;
             }
         }
+        ch.clear();
+        for (int e = head; e != QR_NULL; e = E[e].next) ch.push_back(Tmp{e, 0, E[e].simd, QR_NULL, true});
         lo_after.assign((size_t)n, QR_NULL); lo_self.assign((size_t)n, QR_NULL);
         /* box cull cells (QR_OPF_BOX) only in images whose lists are all short: the packet-walk kernel instance serves them */
         const bool list_boxes = box_ok;
@@ -673,12 +702,7 @@ struct Builder
         if (want_dda && world && (lf & QR_LISTF_DIV)) { build_dda(base, off, n); lf |= QR_LISTF_DDA; any_long = true; }
         list_off[head] = off | lf;
         list_heavy[head] = heavy;
-        if (dedup)
-        {
-            DedupEnt d = { dedup_pool.size(), dk.size(), off | lf, heavy };
-            dedup_pool.insert(dedup_pool.end(), dk.begin(), dk.end());
-            dedup_map.emplace(dkey, d);
-        }
+        if (dedup) dedup_add(dkey, off | lf, heavy);
         return off | lf;
     }
 
@@ -933,8 +957,11 @@ struct Builder
 
 } // namespace
 
-int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
-                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks, bool verify)
+/* one attempt.  assume_short: take every chain for shorter than QR_LONG_CELLS without measuring them first (the engine's scenes:
+ * tens of thousands of tile chains of two or three elements); compile_list throws Restart at the first chain that is not */
+static int program_build_once(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
+                              const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks,
+                              bool verify, bool assume_short, bool &restart)
 {
     static const bool timing = getenv("QR_COMPILE_TIMING") != nullptr;
     struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -967,7 +994,9 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
                 if (is_real(q) && q.srf_t[0] == 1 && q.has_trm == 0 && q.shift == 0 && (q.lst[0] != QR_NULL || q.lst[2] != QR_NULL)) want_grids = true;
             }
         if (want_grids) Eg = E;
+        tick("pre");
         Builder b(v, want_grids ? Eg : E, bs, cull_mode, out.blob);
+        tick("builder");
         {
             const char *de = getenv("QR_DDA");          /* 0 turns the uniform grids off */
             b.dda_min = de ? atoi(de) : 512;
@@ -1012,29 +1041,33 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         b.at<qr_material>(b.o_mat)[n_mat].clamp = 1.0f;
         memcpy(b.at<qr_light>(b.o_lgt), v.lgt, (size_t)n_lgt * sizeof(qr_light));
         memcpy(b.at<uint32_t>(b.o_tex), v.texels, (size_t)n_tex * 4);
+        tick("fixed");
 
         /* box cull cells (QR_OPF_BOX) for images whose lists are all short: no list of such an image can be flagged as a long
          * hierarchy or get a uniform / shadow grid (each needs a chain of >= QR_LONG_CELLS elements), so only packet walks read its cells.
          * QR_BOX=0: spheres only (A/B runs, tests). */
         {
             /* length of the chain behind every element (chains share tails): follow it to an element already known, unwind */
-            static thread_local std::vector<int32_t> len, stack;
-            len.assign(b.E.size(), 0);
             int32_t longest = 0;
             bool ok = true;
-            for (size_t e0 = 0; e0 < b.E.size() && ok; e0++)
+            if (!assume_short)
             {
-                if (len[e0] != 0) continue;
-                stack.clear();
-                int e = (int)e0;
-                while (e != QR_NULL && len[e] == 0)
+                static thread_local std::vector<int32_t> len, stack;
+                len.assign(b.E.size(), 0);
+                for (size_t e0 = 0; e0 < b.E.size() && ok; e0++)
                 {
-                    stack.push_back(e); e = b.E[e].next;
-                    if (stack.size() > b.E.size()) { ok = false; break; }
+                    if (len[e0] != 0) continue;
+                    stack.clear();
+                    int e = (int)e0;
+                    while (e != QR_NULL && len[e] == 0)
+                    {
+                        stack.push_back(e); e = b.E[e].next;
+                        if (stack.size() > b.E.size()) { ok = false; break; }
+                    }
+                    int32_t l = e != QR_NULL ? len[e] : 0;
+                    while (!stack.empty()) { len[stack.back()] = ++l; stack.pop_back(); }
+                    if (l > longest) longest = l;
                 }
-                int32_t l = e != QR_NULL ? len[e] : 0;
-                while (!stack.empty()) { len[stack.back()] = ++l; stack.pop_back(); }
-                if (l > longest) longest = l;
             }
             const char *be = getenv("QR_BOX");
             const bool box_lists = cull_mode >= 3 && !(be && atoi(be) == 0);
@@ -1108,25 +1141,86 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         b.at<DShade>(b.o_shd)[n_srf].mat[0] = b.at<DShade>(b.o_shd)[n_srf].mat[1] = b.o_mat + (uint32_t)n_mat * (uint32_t)sizeof(qr_material);
         for (int k = 0; k < 3; k++) { b.at<DSurf>(b.o_srf)[n_srf].min[k] = -__builtin_inff(); b.at<DSurf>(b.o_srf)[n_srf].max[k] = __builtin_inff(); }
         b.at<DSurf>(b.o_srf)[n_srf].trn = b.srf_off(n_srf);
+        tick("surfaces");
 
         /* wave schedule: one entry {footprint | heaviness << 30, tile-list offset} per wave footprint.
          * heavy = the footprint's tile list holds a reflective or non-opaque surface: those waves can spawn
          * recursion, are started first and get issue priority */
-        std::vector<uint8_t> tile_heavy(T.size(), 0);
+        /* (scratch kept per thread between frames; bound to references once: every use of a thread_local of a shared
+         * library is a call) */
+        static thread_local std::vector<uint8_t> tl_tile_heavy, tl_empty;
+        static thread_local std::vector<int> tl_fb, tl_blk_of;
+        static thread_local std::vector<std::vector<uint32_t>> tl_part;    /* [3 * k + class] */
+        static thread_local std::vector<uint32_t *> tl_cur;                 /* write cursors into part[] */
+        std::vector<uint8_t> &tile_heavy = tl_tile_heavy, &empty = tl_empty;
+        std::vector<int> &fb = tl_fb, &blk_of = tl_blk_of;
+        std::vector<std::vector<uint32_t>> &part = tl_part;
+        std::vector<uint32_t *> &cur = tl_cur;
+        tile_heavy.resize(T.size());
         for (size_t t = 0; t < T.size(); t++) tile_heavy[t] = T[t] != QR_NULL ? b.list_heavy[T[t]] : 0;
+        /* The drop-in path launches block by block (K horizontal blocks of footprint rows) and copies block k back while block
+         * k + 1 renders: the entries are collected per block, recursion-capable footprints first, then the others, then the
+         * clear runs */
+        const int K = sched_blocks > 1 ? std::min(sched_blocks, std::max(1, nby)) : 1;
+        fb.resize((size_t)K + 1); blk_of.resize((size_t)nby);
+        for (int k = 0; k <= K; k++) fb[k] = (int)((long long)nby * k / K);
+        for (int k = 0; k < K; k++) for (int y = fb[k]; y < fb[k + 1]; y++) blk_of[y] = k;
+        if (part.size() < (size_t)K * 3) part.resize((size_t)K * 3);
+        cur.resize((size_t)K * 3);
+        for (int i = 0; i < K * 3; i++)
+        {
+            const size_t cap = (size_t)(fb[i / 3 + 1] - fb[i / 3]) * nbx * 2;
+            if (part[i].size() < cap) part[i].resize(cap);
+            cur[i] = part[i].data();
+        }
+        tick("s-prep");
         {
             /* footprints are enumerated tile by tile (32x8 pixel groups) to keep neighbours together */
             const int gx = 32 / fw, gy = 8 / fh;
             const bool nest = frm.tile_w == 32 && frm.tile_h == 8;      /* group (tx, ty) IS tile (tx, ty) */
-            std::vector<uint32_t> &hv_ent = out.order, lt_ent;
-            hv_ent.clear();
-            hv_ent.reserve(n_sched * 2); lt_ent.reserve(n_sched * 2);
             /* footprints over an empty tile only have zeros to store: runs of them along a row share ONE wave (schedule head
              * = run length, 1..QR_CLEAR_RUN_MAX: values below 256 are no list offsets).  Half of demo scene 1's 32 400
              * footprints at 1080p are such; QR_CLEAR_RUN=1 gives every one its own wave again */
             static const int clear_run = []() { const char *e = getenv("QR_CLEAR_RUN"); const int r = e ? atoi(e) : QR_CLEAR_RUN_MAX;
                                                 return r < 1 ? 1 : (r > QR_CLEAR_RUN_MAX ? QR_CLEAR_RUN_MAX : r); }();
-            std::vector<uint8_t> empty((size_t)nbx * nby, 0);
+            const bool plain = nest && gy == 1;
+            if (plain)
+            {
+                /* the plain frame: a row of tiles is a row of footprints, gx of them per tile with the tile's list */
+                for (int by = 0; by < nby; by++)
+                {
+                    uint32_t **c3 = &cur[(size_t)blk_of[by] * 3];
+                    uint32_t *p_hv = c3[0], *p_lt = c3[1], *p_cl = c3[2];
+                    const bool in_rows = by < frm.tls_col;
+                    const uint32_t *t_off = tile_off.data() + (size_t)by * frm.tls_row;
+                    const uint8_t *t_hv = tile_heavy.data() + (size_t)by * frm.tls_row;
+                    int run0 = 0, run = 0;                  /* the clear run being collected: first footprint, length */
+                    for (int tx = 0; tx * gx < nbx; tx++)
+                    {
+                        const bool in = in_rows && tx < frm.tls_row;
+                        const uint32_t head = in ? t_off[tx] : QR_SCHED_PER_LANE;
+                        const uint32_t hv = in ? t_hv[tx] : 0u;
+                        const int bx0 = tx * gx, cnt = std::min(gx, nbx - bx0);
+                        if (head == 0)
+                        {
+                            for (int i = 0; i < cnt; i++)
+                            {
+                                if (run == 0) run0 = bx0 + i;
+                                if (++run == clear_run) { p_cl[0] = (uint32_t)run0 | ((uint32_t)by << 14); p_cl[1] = (uint32_t)run; p_cl += 2; run = 0; }
+                            }
+                            continue;
+                        }
+                        if (run) { p_cl[0] = (uint32_t)run0 | ((uint32_t)by << 14); p_cl[1] = (uint32_t)run; p_cl += 2; run = 0; }
+                        uint32_t *&dst = hv ? p_hv : p_lt;
+                        const uint32_t ent = ((uint32_t)by << 14) | ((hv & 3u) << 30);
+                        for (int i = 0; i < cnt; i++) { dst[0] = ent | (uint32_t)(bx0 + i); dst[1] = head; dst += 2; }
+                    }
+                    if (run) { p_cl[0] = (uint32_t)run0 | ((uint32_t)by << 14); p_cl[1] = (uint32_t)run; p_cl += 2; }
+                    c3[0] = p_hv; c3[1] = p_lt; c3[2] = p_cl;
+                }
+            }
+            else empty.assign((size_t)nbx * nby, 0);
+            if (!plain)
             for (int ty = 0; ty * gy < nby; ty++)
                 for (int tx = 0; tx * gx < nbx; tx++)
                 {
@@ -1137,10 +1231,19 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
                         g_hv = tile_heavy[t]; g_head = tile_off[t];
                     }
                     for (int j = 0; j < gy; j++)
+                    {
+                        const int by = ty * gy + j;
+                        if (by >= nby) break;
+                        uint32_t **row3 = &cur[(size_t)blk_of[by] * 3];
+                        if (nest && g_head == 0)
+                        {
+                            for (int i = 0; i < gx && tx * gx + i < nbx; i++) empty[(size_t)by * nbx + tx * gx + i] = 1;
+                            continue;
+                        }
                         for (int i = 0; i < gx; i++)
                         {
-                            const int bx = tx * gx + i, by = ty * gy + j;
-                            if (bx >= nbx || by >= nby) continue;
+                            const int bx = tx * gx + i;
+                            if (bx >= nbx) break;
                             int hv = g_hv; uint32_t head = g_head;
                             if (!nest)
                             {
@@ -1154,54 +1257,56 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
                             }
                             if (head == 0) { empty[(size_t)by * nbx + bx] = 1; continue; }
                             const uint32_t ent = (uint32_t)bx | ((uint32_t)by << 14) | ((uint32_t)(hv & 3) << 30);
-                            std::vector<uint32_t> &dst = hv ? hv_ent : lt_ent;
-                            dst.push_back(ent); dst.push_back(head);
+                            uint32_t *&dst = row3[hv ? 0 : 1];
+                            dst[0] = ent; dst[1] = head; dst += 2;
                         }
+                    }
                 }
-            hv_ent.insert(hv_ent.end(), lt_ent.begin(), lt_ent.end());
-            for (int by = 0; by < nby; by++)
+            tick("s-enum");
+            for (int by = 0; by < nby && !plain; by++)
+            {
+                uint32_t *&dst = cur[(size_t)blk_of[by] * 3 + 2];
+                const uint8_t *em = empty.data() + (size_t)by * nbx;
                 for (int bx = 0; bx < nbx; )
                 {
-                    if (!empty[(size_t)by * nbx + bx]) { bx++; continue; }
+                    if (!em[bx]) { bx++; continue; }
                     int run = 1;
-                    while (run < clear_run && bx + run < nbx && empty[(size_t)by * nbx + bx + run]) run++;
-                    hv_ent.push_back((uint32_t)bx | ((uint32_t)by << 14));
-                    hv_ent.push_back((uint32_t)run);
+                    while (run < clear_run && bx + run < nbx && em[bx + run]) run++;
+                    dst[0] = (uint32_t)bx | ((uint32_t)by << 14); dst[1] = (uint32_t)run; dst += 2;
                     bx += run;
                 }
-        }
-        tick("schedule");
-        if (out.order.size() > n_sched * 2 || (out.order.size() & 1)) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
-        const size_t n_waves = out.order.size() / 2;        /* schedule entries: one per wave (fewer than footprints: clear runs) */
-        out.block_first.clear(); out.block_row.clear();
-        if (sched_blocks > 1)
-        {
-            /* group the schedule by horizontal block (stable: heavy footprints stay first inside a block), so that the
-             * drop-in path can launch block by block and copy block k back while block k + 1 renders */
-            const int K = std::min(sched_blocks, std::max(1, nby));
-            std::vector<std::vector<uint32_t>> part((size_t)K);
-            for (auto &pv : part) pv.reserve(out.order.size() / K + 64);
-            std::vector<int> fb((size_t)K + 1);
-            for (int k = 0; k <= K; k++) fb[k] = (int)((long long)nby * k / K);
-            std::vector<int> blk_of((size_t)nby);
-            for (int k = 0; k < K; k++) for (int y = fb[k]; y < fb[k + 1]; y++) blk_of[y] = k;
-            for (size_t i = 0; i + 1 < out.order.size(); i += 2)
-            {
-                const int by = (int)((out.order[i] >> 14) & 0x3FFFu);
-                std::vector<uint32_t> &pv = part[blk_of[by]];
-                pv.push_back(out.order[i]); pv.push_back(out.order[i + 1]);
             }
+        }
+        tick("s-clear");
+        {
+            size_t total = 0;
+            for (int i = 0; i < K * 3; i++) total += (size_t)(cur[i] - part[i].data());
+            if (total > n_sched * 2 || (total & 1)) throw Fail{QR_ERR_ARG, "schedule size mismatch"};
+            out.order.resize(total);
+            out.block_first.clear(); out.block_row.clear();
             size_t pos = 0;
             for (int k = 0; k < K; k++)
             {
-                out.block_first.push_back((uint32_t)(pos / 2));
-                out.block_row.push_back((uint32_t)std::min(fb[k] * fh, frm.frm_h));
-                std::copy(part[k].begin(), part[k].end(), out.order.begin() + pos);
-                pos += part[k].size();
+                if (sched_blocks > 1)
+                {
+                    out.block_first.push_back((uint32_t)(pos / 2));
+                    out.block_row.push_back((uint32_t)std::min(fb[k] * fh, frm.frm_h));
+                }
+                for (int c = 0; c < 3; c++)
+                {
+                    const size_t cnt = (size_t)(cur[(size_t)k * 3 + c] - part[(size_t)k * 3 + c].data());
+                    if (cnt) memcpy(out.order.data() + pos, part[(size_t)k * 3 + c].data(), cnt * 4);
+                    pos += cnt;
+                }
             }
-            out.block_first.push_back((uint32_t)(pos / 2));
-            out.block_row.push_back((uint32_t)frm.frm_h);
+            if (sched_blocks > 1)
+            {
+                out.block_first.push_back((uint32_t)(pos / 2));
+                out.block_row.push_back((uint32_t)frm.frm_h);
+            }
         }
+        tick("schedule");
+        const size_t n_waves = out.order.size() / 2;        /* schedule entries: one per wave (fewer than footprints: clear runs) */
         memcpy(b.at<uint32_t>(o_ord), out.order.data(), out.order.size() * 4);
 
         DevHeader &h = *b.at<DevHeader>(0);
@@ -1220,11 +1325,21 @@ int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, cons
         b.at<DevHeader>(0)->img_flags = b.any_box ? QR_IMG_BOXES : 0u;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
+    catch (const Builder::Restart &) { restart = true; return QR_OK; }
     tick("finish");
     if (!verify) return QR_OK;
     const int vrc = qr_program_verify(out, err);
     tick("verify");
     return vrc;
+}
+
+int qr_program_build(const qr_scene_view &v, const std::vector<qr_elem> &E, const std::vector<int32_t> &T,
+                     const qr_frame &frm, const std::vector<BSphere> &bs, QrProgram &out, std::string &err, int sched_blocks, bool verify)
+{
+    bool restart = false;
+    int rc = program_build_once(v, E, T, frm, bs, out, err, sched_blocks, verify, true, restart);
+    if (restart) rc = program_build_once(v, E, T, frm, bs, out, err, sched_blocks, verify, false, restart);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -1420,12 +1535,23 @@ extern "C" int qr_program_stats(const void *blob, uint64_t size, qr_program_info
     const int rc0 = qr_scene_view_init(&v, blob, size);
     if (rc0 != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc0) + ")");
     std::string err;
+    static const bool timing = getenv("QR_COMPILE_TIMING") != nullptr;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto tick = [&](const char *what) {
+        if (!timing) return;
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "  compile %-10s %.3f ms\n", what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+        ts0 = t1;
+    };
     int rc = qr_snapshot_validate(v, err);
     if (rc != QR_OK) return qr_fail(rc, err);
+    tick("validate");
     std::vector<BSphere> bs;
     qr_bound_spheres(v, bs);
+    tick("bounds");
     std::vector<qr_elem> E(v.elm, v.elm + v.hdr->n_elm);
     std::vector<int32_t> T(v.tiles, v.tiles + v.hdr->n_tiles);
+    tick("copies");
     QrProgram p;
     rc = qr_program_build(v, E, T, *v.frame, bs, p, err);
     if (rc != QR_OK) return qr_fail(rc, err);
