@@ -4,7 +4,9 @@
  */
 #include "qr_internal.h"
 
+#include <algorithm>
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 
@@ -66,6 +68,22 @@ extern "C" int qr_capture_snapshot(const void *s_inf, const qr_abi_desc *abi, co
     std::string err;
     int rc = qr_flatten_impl(s_inf, abi, out, err, &g_capture_map);
     if (rc != QR_OK) return qr_fail(rc, err);
+    if (const char *reps = getenv("QR_FLATTEN_TIMING"))     /* development aid: the flattener's time on this scene, host only */
+    {
+        std::vector<double> t;
+        std::vector<uint8_t> again;
+        for (int i = 0, n = atoi(reps); i < n; i++)
+        {
+            struct timespec a, b;
+            clock_gettime(CLOCK_MONOTONIC, &a);
+            qr_flatten_impl(s_inf, abi, again, err);
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            t.push_back((double)(b.tv_sec - a.tv_sec) * 1e3 + (double)(b.tv_nsec - a.tv_nsec) * 1e-6);
+        }
+        std::sort(t.begin(), t.end());
+        if (!t.empty()) fprintf(stderr, "flatten: median %.3f ms, min %.3f ms over %zu calls, %zu bytes, %s\n", t[t.size() / 2], t[0], t.size(),
+                                again.size(), again == out ? "same bytes" : "DIFFERENT bytes");
+    }
     FILE *f = fopen(path, "wb");
     if (f == nullptr) return qr_fail(QR_ERR_IO, std::string("cannot open ") + path);
     size_t n = fwrite(out.data(), 1, out.size(), f);

@@ -14,6 +14,7 @@
  */
 #include "qr_internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -75,45 +76,66 @@ enum ListKind { LIST_SURFACES, LIST_CLIPPERS, LIST_LIGHTS };
  */
 class PtrMap
 {
-    std::vector<uint64_t> keys;         /* 0 = empty (NULL is never a key) */
-    std::vector<int32_t>  vals;
+    /* Which slots are in use is kept apart, one bit per slot: the flattener mostly looks up cells it has NOT seen (every list
+     * cell of a frame is entered once), and such a lookup then ends in the bit set -- a few KB that stay in the first-level
+     * cache -- without reading the table; clear() zeroes the bits and leaves the table as it is. */
+    struct Slot { uint64_t key; int32_t val; int32_t pad; };
+    std::vector<Slot> tab;
+    std::vector<uint64_t> occ;
     size_t used = 0;
     static size_t slot(uint64_t k, size_t mask) { return (size_t)((k >> 4) * 0x9E3779B97F4A7C15ull >> 17) & mask; }
-    void grow()
+    bool in_use(size_t j) const { return (occ[j >> 6] >> (j & 63)) & 1u; }
+    void rebuild(size_t n)
     {
-        const size_t n = keys.empty() ? 1024 : keys.size() * 2;
-        std::vector<uint64_t> k(n, 0); std::vector<int32_t> v(n, 0);
-        for (size_t i = 0; i < keys.size(); i++)
-            if (keys[i]) { size_t j = slot(keys[i], n - 1); while (k[j]) j = (j + 1) & (n - 1); k[j] = keys[i]; v[j] = vals[i]; }
-        keys.swap(k); vals.swap(v);
+        std::vector<Slot> t(n, Slot{0, 0, 0});
+        std::vector<uint64_t> o(n / 64, 0);
+        for (size_t i = 0; i < tab.size(); i++)
+            if (in_use(i))
+            {
+                size_t j = slot(tab[i].key, n - 1);
+                while ((o[j >> 6] >> (j & 63)) & 1u) j = (j + 1) & (n - 1);
+                t[j] = tab[i]; o[j >> 6] |= (uint64_t)1 << (j & 63);
+            }
+        tab.swap(t); occ.swap(o);
     }
 public:
+    void clear() { if (used) std::fill(occ.begin(), occ.end(), (uint64_t)0); used = 0; }
     const int32_t *find(uint64_t key) const
     {
-        if (keys.empty()) return nullptr;
-        const size_t mask = keys.size() - 1;
-        for (size_t j = slot(key, mask); keys[j]; j = (j + 1) & mask) if (keys[j] == key) return &vals[j];
+        if (tab.empty()) return nullptr;
+        const size_t mask = tab.size() - 1;
+        for (size_t j = slot(key, mask); in_use(j); j = (j + 1) & mask) if (tab[j].key == key) return &tab[j].val;
         return nullptr;
     }
     void reserve(size_t n)
     {
         size_t cap = 1024; while (cap < 2 * n) cap *= 2;
-        if (cap > keys.size()) { std::vector<uint64_t> k(cap, 0); std::vector<int32_t> v(cap, 0); keys.swap(k); vals.swap(v); used = 0; }
+        if (cap > tab.size()) rebuild(cap);
+    }
+    /* the value stored for key, or -- when there is none -- val after storing it (fresh = true) */
+    int32_t find_or_put(uint64_t key, int32_t val, bool &fresh)
+    {
+        if ((used + 1) * 2 > tab.size()) rebuild(tab.empty() ? 1024 : tab.size() * 2);
+        const size_t mask = tab.size() - 1;
+        size_t j = slot(key, mask);
+        for (; in_use(j); j = (j + 1) & mask) if (tab[j].key == key) { fresh = false; return tab[j].val; }
+        used++; tab[j] = Slot{key, val, 0}; occ[j >> 6] |= (uint64_t)1 << (j & 63); fresh = true;
+        return val;
     }
     void put(uint64_t key, int32_t val)
     {
-        if ((used + 1) * 2 > keys.size()) grow();
-        const size_t mask = keys.size() - 1;
-        size_t j = slot(key, mask);
-        while (keys[j] && keys[j] != key) j = (j + 1) & mask;
-        if (!keys[j]) used++;
-        keys[j] = key; vals[j] = val;
+        bool fresh;
+        if (find_or_put(key, val, fresh) != val)
+        {
+            const size_t mask = tab.size() - 1;
+            for (size_t j = slot(key, mask); ; j = (j + 1) & mask) if (in_use(j) && tab[j].key == key) { tab[j].val = val; break; }
+        }
     }
     int32_t at(uint64_t key) const { const int32_t *p = find(key); return p ? *p : QR_NULL; }
     void by_index(std::vector<uint64_t> &out, size_t n) const      /* out[value] = key */
     {
         out.assign(n, 0);
-        for (size_t j = 0; j < keys.size(); j++) if (keys[j] && (size_t)vals[j] < n) out[(size_t)vals[j]] = keys[j];
+        for (size_t i = 0; i < tab.size(); i++) if (in_use(i) && (size_t)tab[i].val < n) out[(size_t)tab[i].val] = tab[i].key;
     }
 };
 
@@ -128,7 +150,26 @@ struct Walker
     std::vector<uint32_t>    texels;
     PtrMap srf_ix, mat_ix, lgt_ix, elm_ix, tex_ix;
     std::deque<uint64_t> srf_todo;
+    std::vector<uint64_t> fresh_pool;       /* walk_list's new cells, stacked (a light list walks shadow lists inside) */
+    std::vector<int32_t> tiles;
     std::string err;
+
+    /* The storage of a thread's walkers goes from frame to frame: a Walker is a local object (the optimiser keeps its fields
+     * in registers; one reached through a thread_local reference ran 1.5x slower) that borrows the vectors and maps of the
+     * thread's store for the call and hands them back emptied, capacity kept. */
+    void swap_storage(Walker &o)
+    {
+        srf.swap(o.srf); mat.swap(o.mat); lgt.swap(o.lgt); elm.swap(o.elm); texels.swap(o.texels);
+        std::swap(srf_ix, o.srf_ix); std::swap(mat_ix, o.mat_ix); std::swap(lgt_ix, o.lgt_ix); std::swap(elm_ix, o.elm_ix); std::swap(tex_ix, o.tex_ix);
+        fresh_pool.swap(o.fresh_pool); tiles.swap(o.tiles);
+    }
+    void reset()
+    {
+        srf.clear(); mat.clear(); lgt.clear(); elm.clear(); texels.clear();
+        srf_ix.clear(); mat_ix.clear(); lgt_ix.clear(); elm_ix.clear(); tex_ix.clear();
+        srf_todo.clear(); fresh_pool.clear(); tiles.clear(); err.clear();
+        pt = false;
+    }
 
     /* surface tag, srf_SRF_T(TAG) = DP(Q*0x240 + 0x0C), tracer.h:957-958 */
     int32_t srf_tag(uint64_t p) const
@@ -237,33 +278,33 @@ struct Walker
     int32_t walk_list(uint64_t head, ListKind kind)
     {
         if (head == 0) return QR_NULL;
-        if (const int32_t *known = elm_ix.find(head)) return *known;
 
         /* cells new to this walk get consecutive indices from `base`, so inside the run `next` is the
          * following index and only the run's exit (NULL or a cell met before) needs a lookup: this runs
          * for every tile list of every frame in the drop-in path */
-        std::vector<uint64_t> fresh;
-        fresh.reserve(16);
+        const size_t f0 = fresh_pool.size();
         const int32_t base = (int32_t)elm.size();
         int32_t exit_ix = QR_NULL;
         for (uint64_t p = head; p != 0; )
         {
-            if (const int32_t *k = elm_ix.find(p)) { exit_ix = *k; break; }
-            int32_t ix = (int32_t)elm.size();
-            elm_ix.put(p, ix);
+            bool is_new;
+            const int32_t ix = elm_ix.find_or_put(p, (int32_t)elm.size(), is_new);
+            if (!is_new) { exit_ix = ix; break; }
             qr_elem e; e.simd = QR_NULL; e.data = QR_NULL; e.next = QR_NULL; e.kind = 0;
             elm.push_back(e);
-            fresh.push_back(p);
+            fresh_pool.push_back(p);
             p = rd_elem(a, p).next;
             if (elm.size() > (size_t)64 * 1024 * 1024) { err = "element list too long / cyclic"; return QR_NULL; }
         }
+        const size_t n_fresh = fresh_pool.size() - f0;
+        if (n_fresh == 0) return exit_ix;           /* the head is a cell met before: a list (or tail) shared with an earlier walk */
 
-        for (size_t fi = 0; fi < fresh.size(); fi++)
+        for (size_t fi = 0; fi < n_fresh; fi++)
         {
-            const uint64_t p = fresh[fi];
+            const uint64_t p = fresh_pool[f0 + fi];
             ElemRaw r = rd_elem(a, p);
             qr_elem e;
-            e.next = fi + 1 < fresh.size() ? base + (int32_t)fi + 1 : exit_ix;
+            e.next = fi + 1 < n_fresh ? base + (int32_t)fi + 1 : exit_ix;
             e.kind = 0;
             e.data = QR_NULL;
             e.simd = QR_NULL;
@@ -320,13 +361,14 @@ struct Walker
 
         if (kind == LIST_LIGHTS)
         {
-            for (size_t fi = 0; fi < fresh.size(); fi++)
+            for (size_t fi = 0; fi < n_fresh; fi++)
             {
-                ElemRaw r = rd_elem(a, fresh[fi]);
+                ElemRaw r = rd_elem(a, fresh_pool[f0 + fi]);
                 int32_t sh = walk_list((uint64_t)r.data, LIST_SURFACES);
                 elm[(size_t)base + fi].data = sh;
             }
         }
+        fresh_pool.resize(f0);
         return base;
     }
 
@@ -440,7 +482,14 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     if (abi->quads != 1 && abi->quads != 2 && abi->quads != 4 && abi->quads != 8 && abi->quads != 16)
     { err = "bad quads"; return QR_ERR_ABI; }
 
+    static thread_local Walker tl_store;
     Walker w;
+    struct Lend                     /* storage in for the call, back (emptied) on every way out */
+    {
+        Walker &w, &st;
+        Lend(Walker &w_, Walker &st_) : w(w_), st(st_) { w.swap_storage(st); }
+        ~Lend() { w.reset(); w.swap_storage(st); }
+    } lend(w, tl_store);
     w.a.Q = abi->quads;
     w.a.P = abi->pointer_bits / 32;
     w.a.ps = (size_t)w.a.P * 4;
@@ -513,7 +562,8 @@ int qr_flatten_impl(const void *s_inf, const qr_abi_desc *abi, std::vector<uint8
     double pt = now();
     auto phase = [&](const char *n) { if (ph) { const double t = now(); fprintf(stderr, "flatten phase %-10s %.3f ms\n", n, t - pt); pt = t; } };
     /* primary lists: per-tile heads (tracer.cpp:1182-1194, 1328-1339) and inf_LST */
-    std::vector<int32_t> tiles((size_t)f.tls_row * f.tls_col, QR_NULL);
+    std::vector<int32_t> &tiles = w.tiles;
+    tiles.assign((size_t)f.tls_row * f.tls_col, QR_NULL);
     w.elm_ix.reserve(tiles.size() * 2 + 4096);          /* before anything is in it: no rehash while walking */
     w.elm.reserve(tiles.size() * 2 + 4096);
     const uint8_t *tl = (const uint8_t *)(uintptr_t)p_tiles;
