@@ -277,8 +277,12 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
 
     T.assign((size_t)n_tiles, QR_NULL);
     if (ent.empty()) return QR_OK;
+    const bool bin_verbose = getenv("QR_VERBOSE") && atoi(getenv("QR_VERBOSE")) >= 2;
+    double bin_t = now_ms();
+    auto bin_phase = [&](const char *name) { if (bin_verbose) { const double t = now_ms(); fprintf(stderr, "  binning %-10s %.3f ms\n", name, t - bin_t); bin_t = t; } };
+    bin_phase("(start)");
     if (const char *vb = getenv("QR_VERBOSE"))
-        if (atoi(vb) >= 2)
+        if (atoi(vb) >= 3)
             for (const BinEntry &b : ent)
                 if (!b.marker)
                     fprintf(stderr, "bin entry: surface %d tiles %d (x %d..%d, y %d..%d)\n", b.simd,
@@ -292,11 +296,13 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
     BIN_TRY(hipMalloc((void **)&d_off, (size_t)n_tiles * 4));
     BIN_TRY(hipMalloc((void **)&d_heads, (size_t)n_tiles * 4));
     BIN_TRY(hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(BinEntry), hipMemcpyHostToDevice));
+    bin_phase("alloc+h2d");
     const dim3 blk(256), grd((unsigned)((n_tiles + 255) / 256));
     hipLaunchKernelGGL((qr_bin_kernel<false>), grd, blk, 0, 0, d_ent, (int)ent.size(), frm.tls_row, n_tiles, d_cnt, (const int32_t *)nullptr, (qr_elem *)nullptr, (int32_t *)nullptr, 0);
     BIN_TRY(hipGetLastError());
     std::vector<int32_t> cnt((size_t)n_tiles), off((size_t)n_tiles);
     BIN_TRY(hipMemcpy(cnt.data(), d_cnt, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
+    bin_phase("count");
     uint64_t total = 0;
     for (int i = 0; i < n_tiles; i++) { off[i] = (int32_t)total; total += (uint32_t)cnt[i]; }
     if (total + E.size() > 0x7FFFFFF0ull) { cleanup(); return qr_fail(QR_ERR_NOMEM, "tile lists exceed the 31-bit cell index space"); }
@@ -311,7 +317,9 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
         BIN_TRY(hipMemcpy(E.data() + cell_base, d_cells, (size_t)total * sizeof(qr_elem), hipMemcpyDeviceToHost));
         BIN_TRY(hipMemcpy(T.data(), d_heads, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
     }
+    bin_phase("fill+d2h");
     cleanup();
+    bin_phase("free");
 #undef BIN_TRY
     if (getenv("QR_VERBOSE"))
         fprintf(stderr, "tile binning: %zu camera-list entries x %d tiles (%dx%d px) -> %llu cells\n", ent.size(), n_tiles, frm.tile_w, frm.tile_h, (unsigned long long)total);

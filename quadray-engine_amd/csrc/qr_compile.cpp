@@ -199,15 +199,29 @@ struct ListFilter
         }
     }
 
+    /*
+     * A filtered chain before it is part of E: its elements with `next` (and the `data` of kept array heads, flagged in
+     * `local`) as indices INTO THE RUN.  filter_run only reads the filter and E, so many threads may filter one chain at a time;
+     * append() then makes a run part of E, one after the other.
+     */
+    struct Run { std::vector<qr_elem> el; std::vector<uint8_t> local; };
+    enum { SOURCE_LIST = -2 };              /* filter_run's result when nothing was dropped: the source chain itself */
+
     /* keep(sphere, bounded) -> may a surface with this bound matter; returns the new list's head */
     template <typename Pred>
     int filter(Pred keep)
     {
-        return filter_nodes([&](int i) {
+        Run run;
+        return append(run, filter_run(keep, run));
+    }
+    template <typename Pred>
+    int filter_run(Pred keep, Run &run) const
+    {
+        return filter_nodes_run([&](int i) {
             const Node &nd = ch[i];
             if (nd.head) return !nd.bounded || keep(nd.bound, true);
             return keep(nd.bound, nd.bounded);
-        });
+        }, run);
     }
 
     /* keep(i) by position in the chain: for an array element "may any member matter" (false prunes the array without
@@ -217,7 +231,30 @@ struct ListFilter
     template <typename Pred>
     int filter_nodes(Pred keep)
     {
-        const size_t e_mark = E.size();
+        Run run;
+        return append(run, filter_nodes_run(keep, run));
+    }
+
+    /* the run becomes the tail of E; head as filter_nodes_run returned it -> the chain's head in E */
+    int append(const Run &run, int head)
+    {
+        if (head == SOURCE_LIST) return ch[0].e;
+        const int base = (int)E.size();
+        for (size_t i = 0; i < run.el.size(); i++)
+        {
+            qr_elem c = run.el[i];
+            if (c.next != QR_NULL) c.next += base;
+            if (run.local[i] && c.data != QR_NULL) c.data += base;
+            E.push_back(c);
+        }
+        return head == QR_NULL ? QR_NULL : head + base;
+    }
+
+    template <typename Pred>
+    int filter_nodes_run(Pred keep, Run &run) const
+    {
+        run.el.clear(); run.local.clear();
+        std::vector<qr_elem> &R = run.el;
         bool dropped = false;
         struct Open { int idx; int out; int last; };
         std::vector<Open> open;
@@ -225,16 +262,16 @@ struct ListFilter
         auto emit = [&](int src_e, int data) {
             qr_elem c = E[src_e];
             c.data = data; c.next = QR_NULL;
-            E.push_back(c);
-            const int ix = (int)E.size() - 1;
-            if (tail != QR_NULL) E[tail].next = ix; else head = ix;
+            R.push_back(c); run.local.push_back(0);
+            const int ix = (int)R.size() - 1;
+            if (tail != QR_NULL) R[tail].next = ix; else head = ix;
             tail = ix;
             return ix;
         };
         auto close_until = [&](int i) {
             while (!open.empty() && open.back().last < i)
             {
-                if (open.back().out != QR_NULL) E[open.back().out].data = tail;      /* last kept member */
+                if (open.back().out != QR_NULL) { R[open.back().out].data = tail; run.local[open.back().out] = 1; }     /* last kept member */
                 open.pop_back();
             }
         };
@@ -260,21 +297,21 @@ struct ListFilter
             i++;
         }
         close_until(n);
-        if (!dropped && n > 0) { E.resize(e_mark); return ch[0].e; }
+        if (!dropped && n > 0) { R.clear(); run.local.clear(); return SOURCE_LIST; }
         /* a list that keeps only a handful of surfaces does not need their bounding-volume elements (AR_ptr elements
          * only skip work, tracer.cpp:3955-4054): written flat it is a fraction of the cells.  Trnode elements stay. */
         int kept = 0;
-        for (int e = head; e != QR_NULL; e = E[e].next) if (is_real(v.srf[E[e].simd])) kept++;
+        for (int e = head; e != QR_NULL; e = R[e].next) if (is_real(v.srf[R[e].simd])) kept++;
         if (kept <= QR_FLAT_LIST_MAX)
         {
             int nh = QR_NULL, nt = QR_NULL;
             for (int e = head; e != QR_NULL; )
             {
-                const int nx = E[e].next;
-                if ((E[e].kind & 3) != 1)
+                const int nx = R[e].next;
+                if ((R[e].kind & 3) != 1)
                 {
-                    if (nt != QR_NULL) E[nt].next = e; else nh = e;
-                    nt = e; E[e].next = QR_NULL;
+                    if (nt != QR_NULL) R[nt].next = e; else nh = e;
+                    nt = e; R[e].next = QR_NULL;
                 }
                 e = nx;
             }
@@ -315,6 +352,15 @@ struct HullPred
         return dmin * shrink <= xr + tc * sr * 1.001 + 1e-3;
     }
 };
+
+/* worker threads of the host passes: QR_HOST_THREADS, else the machine's (at most 16) */
+static int host_threads()
+{
+    const char *te = getenv("QR_HOST_THREADS");
+    int n = te ? atoi(te) : (int)std::thread::hardware_concurrency();
+    if (n > 16) n = 16;
+    return n < 1 ? 1 : n;
+}
 
 struct Builder
 {
@@ -913,16 +959,39 @@ struct Builder
          * at any sane scale), and the shadow ray starts at the world-space hit, the same point up to rounding */
         const double pad_a = 2e-3 * ca + 1e-3, pad_b = 2e-3 * cb + 1e-3;
         const double pr = __builtin_sqrt((0.5 * ca + pad_a) * (0.5 * ca + pad_a) + (0.5 * cb + pad_b) * (0.5 * cb + pad_b)) + 1e-3;
-        for (int j = 0; j < ny; j++)
-            for (int i = 0; i < nx; i++)
+        /* the chains of the cells: filtered by worker threads (a cell's filter reads the chain and nothing else: 16 us each,
+         * 4 x 4 096 of them are 0.27 s of config 5's upload on one core), then appended to E and compiled in cell order -- the
+         * image a single thread builds.  QR_HOST_THREADS=1: one thread. */
+        const int n_cells = nx * ny;
+        std::vector<ListFilter::Run> runs((size_t)n_cells);
+        std::vector<int> heads((size_t)n_cells, QR_NULL);
+        auto filter_cells = [&](int c0, int c1) {
+            for (int c = c0; c < c1; c++)
             {
+                const int i = c % nx, j = c / nx;
                 double pc[3] = { s.pos[0], s.pos[1], s.pos[2] };
                 pc[a] += lo_a + (i + 0.5) * ca; pc[b] += lo_b + (j + 0.5) * cb;
                 const HullPred pred(v.lgt[lg].pos, pc, pr);
-                const int h = lf.filter(pred);
-                table[(size_t)j * nx + i] = compile_list(h);
-                n_grid_lists++;
+                heads[(size_t)c] = lf.filter_run(pred, runs[(size_t)c]);
             }
+        };
+        int n_thr = host_threads();
+        if (n_thr > n_cells / 64) n_thr = n_cells / 64;
+        if (n_thr <= 1) filter_cells(0, n_cells);
+        else
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < n_thr; t++)
+                pool.emplace_back(filter_cells, (int)((long long)n_cells * t / n_thr), (int)((long long)n_cells * (t + 1) / n_thr));
+            for (std::thread &t : pool) t.join();
+        }
+        for (int c = 0; c < n_cells; c++)
+        {
+            const int h = lf.append(runs[(size_t)c], heads[(size_t)c]);
+            runs[(size_t)c] = ListFilter::Run();
+            table[(size_t)c] = compile_list(h);
+            n_grid_lists++;
+        }
         g.table = alloc(table.size() * 4, 4);
         memcpy(at<uint32_t>(g.table), table.data(), table.size() * 4);
         const uint32_t off = alloc(sizeof(CGrid), 32);
@@ -1047,28 +1116,6 @@ static int program_build_once(const qr_scene_view &v, const std::vector<qr_elem>
          * hierarchy or get a uniform / shadow grid (each needs a chain of >= QR_LONG_CELLS elements), so only packet walks read its cells.
          * QR_BOX=0: spheres only (A/B runs, tests). */
         {
-            /* length of the chain behind every element (chains share tails): follow it to an element already known, unwind */
-            int32_t longest = 0;
-            bool ok = true;
-            if (!assume_short)
-            {
-                static thread_local std::vector<int32_t> len, stack;
-                len.assign(b.E.size(), 0);
-                for (size_t e0 = 0; e0 < b.E.size() && ok; e0++)
-                {
-                    if (len[e0] != 0) continue;
-                    stack.clear();
-                    int e = (int)e0;
-                    while (e != QR_NULL && len[e] == 0)
-                    {
-                        stack.push_back(e); e = b.E[e].next;
-                        if (stack.size() > b.E.size()) { ok = false; break; }
-                    }
-                    int32_t l = e != QR_NULL ? len[e] : 0;
-                    while (!stack.empty()) { len[stack.back()] = ++l; stack.pop_back(); }
-                    if (l > longest) longest = l;
-                }
-            }
             const char *be = getenv("QR_BOX");
             const bool box_lists = cull_mode >= 3 && !(be && atoi(be) == 0);
             {
@@ -1079,7 +1126,7 @@ static int program_build_once(const qr_scene_view &v, const std::vector<qr_elem>
                         for (int k = 0; k < 3; k++) big = std::max(big, std::max((double)__builtin_fabsf(bs[i].lo[k]), (double)__builtin_fabsf(bs[i].hi[k])));
                 b.box_pad = (float)(2e-6 * big);
             }
-            b.box_ok = box_lists && ok && longest < QR_LONG_CELLS;
+            b.box_ok = box_lists && assume_short;       /* the second attempt: compile_list met a chain of QR_LONG_CELLS elements */
         }
         tick("setup");
         /* tile lists */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-only: per-phase time of validate + compile of a snapshot (QR_COMPILE_TIMING ticks of csrc/qr_compile.cpp), and a hash
 of the compiled image (QR_DUMP_IMAGE) so that a change to the compiler can be checked to leave the image byte for byte.
-usage: tools/host_compile_time.py [snapshot.qrs.gz] [reps]"""
+usage: tools/host_compile_time.py [snapshot.qrs.gz | synth:N:W:H:DEPTH] [reps]"""
 import gzip, hashlib, importlib, os, re, subprocess, sys, tempfile
 
 def main():
@@ -10,7 +10,11 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if os.environ.get("_QR_CHILD"):
         q = importlib.import_module("quadray-engine_amd")
-        blob = gzip.open(snap).read()
+        if snap.startswith("synth:"):
+            import bench
+            blob = bytes(bench.load_blob(snap))
+        else:
+            blob = gzip.open(snap).read()
         for _ in range(reps):
             q.program_stats(blob)
         return
