@@ -17,6 +17,7 @@
 #include <emmintrin.h>
 #endif
 #include <vector>
+#include <thread>
 #include <mutex>
 #include <map>
 #include <array>

@@ -415,7 +415,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
      * every frame's waves would carry through the whole recursion */
     __shared__ int lds_hit_id[64];
     if (ids != nullptr) lds_hit_id[lane] = -1;
-    int &sp = ou.sp, &mode = ou.mode, &hit_id = ou.hit_id;
+    int &sp = ou.sp, &mode = ou.mode;
     V3 &ret = ou.ret;
     const int depth = lp.depth;
 
