@@ -203,3 +203,32 @@ def test_gpu_rebuilt_lists_of_tiled_snapshots(qr, name):
     d = int((f1.cpu().numpy().view(np.uint32) != (load_frame(name) & 0xFFFFFF)).sum())
     assert d == (6 if name == "swarm_demo02_200_mix_gf" else 0)
     assert bool((i0 == i1).all())
+
+
+def test_compiled_image_does_not_depend_on_the_number_of_host_threads(qr, tmp_path):
+    """The shadow-grid cells are filtered by worker threads (QR_HOST_THREADS) and appended / compiled in cell order, and the
+    list-building pass concatenates its threads' runs in surface order: the device image must be the one a single thread
+    builds, byte for byte (QR_DUMP_IMAGE writes it)."""
+    import hashlib
+    import os
+    kw = dict(n_objects=600, width=160, height=90, depth=3, box=40.0)
+    raw = _synth().make_scene(shadow_lists=False, **kw)
+    digests = {}
+    img = str(tmp_path / "image.bin")
+    old = {k: os.environ.get(k) for k in ("QR_HOST_THREADS", "QR_DUMP_IMAGE")}
+    try:
+        os.environ["QR_DUMP_IMAGE"] = img
+        for thr in ("1", "3", "8"):
+            os.environ["QR_HOST_THREADS"] = thr
+            built = qr.build_lists(raw)
+            info = qr.program_stats(built)
+            assert info.n_grids == 4
+            with open(img, "rb") as f:
+                digests[thr] = (hashlib.sha1(bytes(built)).hexdigest(), hashlib.sha1(f.read()).hexdigest())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert digests["1"] == digests["3"] == digests["8"]
