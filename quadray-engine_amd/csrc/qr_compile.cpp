@@ -1368,7 +1368,9 @@ static int program_build_once(const qr_scene_view &v, const std::vector<qr_elem>
         out.stats = b.st;
         out.has_long_lists = b.any_long;
         out.has_grids = b.n_grids != 0;
-        if (b.box_ok && (b.any_long || b.n_grids != 0)) throw Fail{QR_ERR_ARG, "layout: box cull cells in an image with long lists"};
+        /* box cells and a list the per-lane walkers take (possible only with lowered QR_DDA / QR_GRID thresholds: by default such a
+         * list has QR_LONG_CELLS elements and has ended the first attempt already): build again without box cells */
+        if (b.box_ok && (b.any_long || b.n_grids != 0)) throw Builder::Restart{};
         b.at<DevHeader>(0)->img_flags = b.any_box ? QR_IMG_BOXES : 0u;
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }

@@ -232,3 +232,19 @@ def test_compiled_image_does_not_depend_on_the_number_of_host_threads(qr, tmp_pa
             else:
                 os.environ[k] = v
     assert digests["1"] == digests["3"] == digests["8"]
+
+
+def test_lowered_grid_thresholds_on_a_scene_of_short_lists_compile(qr):
+    """QR_DDA / QR_GRID below QR_LONG_CELLS (a diagnosis setting): lists shorter than 192 elements get grids, so the image needs
+    the per-lane kernel instance and must not carry box cull cells -- the compiler finds that out at the end of its first
+    attempt and builds again without them instead of refusing the scene."""
+    import os
+    built = qr.build_lists(_synth().make_scene(shadow_lists=False, n_objects=120, width=64, height=36, depth=2, box=10.0))
+    plain = qr.program_stats(built)
+    assert plain.n_dda == 0 and plain.n_grids == 0
+    os.environ.update({"QR_DDA": "32", "QR_GRID": "32"})
+    try:
+        low = qr.program_stats(built)
+    finally:
+        del os.environ["QR_DDA"], os.environ["QR_GRID"]
+    assert low.n_dda >= 1 or low.n_grids >= 1
