@@ -412,24 +412,11 @@ static int rebin_tiles(const qr_scene_view &v, const std::vector<BSphere> &bsph,
         hipLaunchKernelGGL((qr_bin_kernel<true>), grd, blk, 0, 0, d_ent, (int)ent.size(), frm.tls_row, frm.tls_col, groups_row, (const int32_t *)d_cand, (const int32_t *)d_goff,
                            d_cnt, (const int32_t *)d_off, d_cells, d_heads, cell_base);
         BIN_TRY(hipGetLastError());
-        /* the cells come back through a page-locked buffer kept per thread (a copy into pageable memory ran at 1 GB/s:
-         * 5.5 of the pass's 8.5 ms on config 5) */
-        static thread_local void *stage = nullptr;
-        static thread_local size_t stage_cap = 0;
-        const size_t cell_bytes = (size_t)total * sizeof(qr_elem), head_bytes = (size_t)n_tiles * 4;
-        if (cell_bytes + head_bytes > stage_cap)
-        {
-            if (stage != nullptr) (void)hipHostFree(stage);
-            stage = nullptr; stage_cap = 0;
-            const size_t want = (cell_bytes + head_bytes) + (cell_bytes + head_bytes) / 2;
-            BIN_TRY(hipHostMalloc(&stage, want, hipHostMallocPortable));
-            stage_cap = want;
-        }
-        BIN_TRY(hipMemcpy(stage, d_cells, cell_bytes, hipMemcpyDeviceToHost));
-        BIN_TRY(hipMemcpy((char *)stage + cell_bytes, d_heads, head_bytes, hipMemcpyDeviceToHost));
+        /* (callers reserve room behind their cells: growing a 32 MB element array by its 5.5 MB of tile cells would copy it --
+         * 5 of the pass's 8.5 ms on config 5) */
         E.resize((size_t)cell_base + total);
-        memcpy(E.data() + cell_base, stage, cell_bytes);
-        memcpy(T.data(), (const char *)stage + cell_bytes, head_bytes);
+        BIN_TRY(hipMemcpy(E.data() + cell_base, d_cells, (size_t)total * sizeof(qr_elem), hipMemcpyDeviceToHost));
+        BIN_TRY(hipMemcpy(T.data(), d_heads, (size_t)n_tiles * 4, hipMemcpyDeviceToHost));
     }
     bin_phase("fill+d2h");
     cleanup();

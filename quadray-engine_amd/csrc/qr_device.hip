@@ -126,7 +126,9 @@ static int build_program(const void *blob, uint64_t size, int device, uint32_t f
     phase("bounds");
     /* working copies: the tile lists (and with them the cell array and the tile geometry of the
      * frame record) are replaced when the binning pass runs */
-    std::vector<qr_elem> E(v.elm, v.elm + v.hdr->n_elm);
+    std::vector<qr_elem> E;
+    if (flags & QR_UPLOAD_REBIN_TILES) E.reserve((size_t)v.hdr->n_elm + (size_t)v.hdr->n_elm / 2 + 65536);     /* room for the tile cells */
+    E.assign(v.elm, v.elm + v.hdr->n_elm);
     std::vector<int32_t> T(v.tiles, v.tiles + v.hdr->n_tiles);
     qr_frame frm = *v.frame;
     if (flags & QR_UPLOAD_REBIN_TILES)
@@ -1238,6 +1240,8 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         static thread_local std::vector<qr_elem> E;
         static thread_local std::vector<int32_t> T;
         qr_bound_spheres(v, bsph);
+        static const bool rebin = []() { const char *v = getenv("QR_REBIN"); return v && atoi(v) != 0; }();
+        if (rebin) E.reserve((size_t)v.hdr->n_elm + (size_t)v.hdr->n_elm / 2 + 65536);      /* room for the tile cells */
         E.assign(v.elm, v.elm + v.hdr->n_elm);
         T.assign(v.tiles, v.tiles + v.hdr->n_tiles);
         qr_frame frm = *v.frame;
@@ -1245,7 +1249,6 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
          * engine may then run without its own tiling, RT_OPTS_TILING).  The frame is the engine's UNTILED picture: on most
          * scenes that is also its tiled one, but where its screen tiling drops a surface from a tile that the surface does
          * cover the two differ, so this is not the drop-in-exact mode */
-        static const bool rebin = []() { const char *v = getenv("QR_REBIN"); return v && atoi(v) != 0; }();
         if (rebin)
         {
             rc = pick_device(devs[0]);
