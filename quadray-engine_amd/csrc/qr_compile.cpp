@@ -1372,6 +1372,7 @@ static int program_build_once(const qr_scene_view &v, const std::vector<qr_elem>
          * list has QR_LONG_CELLS elements and has ended the first attempt already): build again without box cells */
         if (b.box_ok && (b.any_long || b.n_grids != 0)) throw Builder::Restart{};
         b.at<DevHeader>(0)->img_flags = b.any_box ? QR_IMG_BOXES : 0u;
+        b.at<DevHeader>(0)->img_bytes = (uint32_t)out.blob.size();
     }
     catch (const Fail &f) { err = f.msg; return f.rc; }
     catch (const Builder::Restart &) { restart = true; return QR_OK; }

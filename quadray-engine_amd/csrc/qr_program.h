@@ -217,7 +217,8 @@ struct DevHeader
     uint32_t off_order;         /* whole-frame wave schedule                                                */
     uint32_t n_blocks;
     uint32_t img_flags;         /* QR_IMG_*                                                                  */
-    uint32_t pad[10];
+    uint32_t img_bytes;         /* size of the image (the guarded diagnostic build checks cell offsets against it) */
+    uint32_t pad[9];
 };
 #define QR_IMG_BOXES 1u         /* some cull cell carries a box (QR_OPF_BOX): packet walks prepare the slab test */
 

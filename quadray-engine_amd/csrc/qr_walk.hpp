@@ -23,8 +23,10 @@
  */
 typedef unsigned long long lm_t;
 #if defined(QR_STATS) && defined(QR_GUARD)
-/* diagnostic build: a cell offset that cannot be one is recorded (stats[24..27]: tag, offset, previous offset, count) and the walk ends */
-#define QR_GUARD_POS(tag, p, prev, onbad) do { if (((p) & 31u) != 0u || (p) >= 0x10000000u) { \
+/* diagnostic build: a cell offset that cannot be one -- not a multiple of the cell size, or beyond the image (DevHeader::img_bytes; a fixed
+ * 256 MB bound until round 3 flagged the valid offsets of larger images) -- is recorded (stats[24..27]: tag, offset, previous offset,
+ * count) and the walk ends */
+#define QR_GUARD_POS(tag, p, prev, onbad) do { if (((p) & 31u) != 0u || (p) >= ((const QR_CONST DevHeader *)B)->img_bytes) { \
         if (atomicAdd(&stats[27], 1ull) == 0ull) { stats[24] = (tag); stats[25] = (p); stats[26] = (prev); } onbad; } } while (0)
 #else
 #define QR_GUARD_POS(tag, p, prev, onbad) do { } while (0)

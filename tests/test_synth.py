@@ -242,7 +242,7 @@ def test_gpu_random_synth_scenes_match_oracle(qr, oracle, seed, n, box):
 @pytest.mark.gpu
 def test_gpu_guarded_build_finds_no_bad_cell_offset():
     """The QR_STATS + QR_GUARD build of the kernels (every cell offset of the per-lane walks -- walk_div, walk_pool with its
-    hand-over, walk_dda -- checked before it is loaded) renders synthetic crowds of 300 / 2 000 / 10 000 objects and a swarm
+    hand-over, walk_dda -- checked before it is loaded) renders synthetic crowds of 300 / 490 (dense, lowered grid thresholds: a 300 MB image) / 2 000 / 10 000 objects and a swarm
     fixture: no bad offset, frames equal to the oracle's.  (Round 2's memory-access fault was such an offset)"""
     import subprocess
     import sys
@@ -251,4 +251,4 @@ def test_gpu_guarded_build_finds_no_bad_cell_offset():
         pytest.skip("libqrhip_guard.so not built (make -C quadray-engine_amd/csrc guard)")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_guard_check.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("frame_ok 1") == 4 and "QR_GUARD" not in out.stdout, out.stdout
+    assert out.stdout.count("frame_ok 1") == 5 and "QR_GUARD" not in out.stdout, out.stdout

@@ -33,9 +33,21 @@ cases = {
     "synth300_own_lists": synth.make_scene(n_objects=300, width=320, height=240, depth=4, box=20.0),
     "swarm_demo01_240_mix": gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "swarm_demo01_240_mix.qrs.gz"), "rb").read()),
 }
+# a dense cloud with lowered grid thresholds (every list of 64 members gets its uniform grid, the plane its shadow grids): an image of
+# ~300 MB, i.e. valid cell offsets beyond the 256 MB bound the guard had until round 3
+cases["dense490_low_thresholds"] = qr.build_lists(synth.make_scene(shadow_lists=False, n_objects=490, width=320, height=180, depth=6, box=5.96, seed=20076))
 rc = 0
 for name, blob in cases.items():
-    scn = qr.Scene(blob, rebin_tiles=name.startswith("synth"))
+    low = name.endswith("low_thresholds")
+    if low:
+        os.environ.update({"QR_DDA": "64", "QR_GRID": "64"})
+    try:
+        scn = qr.Scene(blob, rebin_tiles=name.startswith("synth"))
+    finally:
+        if low:
+            del os.environ["QR_DDA"], os.environ["QR_GRID"]
+    if low:
+        print(f"{name} image bytes {scn.info.device_bytes}", flush=True)
     frame, counts = scn.render_count()          # the counting launch prints "QR_GUARD n bad cell offsets" on stderr when n != 0
     torch.cuda.synchronize()
     out = frame.cpu().numpy().view(np.uint32)
