@@ -65,14 +65,15 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (vector), counts an FMA as 2
 
 
-def algorithmic_work(snap):
-    """fp32 operations per frame (SURVEY.md 8(d) weights), counted by the CPU oracle when the
-    fixture was made (tests/golden/make_work.py -> work.json); None if not recorded."""
+def all_work(snap):
+    """fp32 operations per frame (SURVEY.md 8(d) weights) of a workload, tests/golden/work.json: "deferred" = counted by the
+    CPU oracle when the fixture was made (tests/golden/make_work.py), "kernel" = counted by the kernel's QR_PROF build
+    (tools/gpu_work.py), "oracle_band" = the oracle's count on a band of rows where it cannot walk the whole frame."""
     try:
         with open(os.path.join(ROOT, "tests", "golden", "work.json")) as f:
-            return json.load(f)[snap]["deferred"]
+            return json.load(f).get(snap, {})
     except Exception:
-        return None
+        return {}
 
 
 def golden_hash(snap):
@@ -221,6 +222,9 @@ def main():
     ap.add_argument("--workload", default="demo1_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="steps (frames per GPU) in flight, each on its own streams")
+    ap.add_argument("--min-region-ms", type=float, default=250.0,
+                    help="repeat the --steps pass back to back until the timed region lasts at least this long")
+    ap.add_argument("--repetitions", type=int, default=0, help="passes of --steps inside the timed region (0: from --min-region-ms)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: gather every frame on rank 0 (north_star's wording) instead of frame f on rank f")
     args = ap.parse_args()
@@ -341,30 +345,82 @@ def main():
         step(i)
     flush()
     torch.cuda.synchronize()
-    if N > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # How long is one pass of --steps?  A region of a millisecond (the driver's --steps 20 at 0.05 ms per step) measures the
+    # ramp and the drain of the launch pipeline, not the steps: the pass is REPEATED back to back inside the one timed region
+    # until the region lasts >= --min-region-ms (0.25 s), HIP events on every stream mark the boundaries between repetitions
+    # (no synchronisation inside the region: the pipeline stays as full as in a long run), and ms_per_step is the MEDIAN
+    # repetition.  The whole region is still bracketed by barrier + synchronize, and its own mean is reported beside it.
     t0 = time.perf_counter()
-    state["timed"] = True
     for i in range(args.steps):
         step(i)
     flush()
+    torch.cuda.synchronize()
+    probe_ms = (time.perf_counter() - t0) * 1e3
+    if N > 1:
+        # every rank must run the same number of passes (the exchanges are collective): agree on the slowest rank's probe
+        t = torch.tensor([probe_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        probe_ms = float(t.item())
+    R = 1
+    if args.repetitions > 0:
+        R = args.repetitions
+    elif probe_ms < args.min_region_ms:
+        R = int(min(100000, max(3, -(-args.min_region_ms // max(probe_ms, 1e-3)))))
+    all_streams = streams + ([comm] if N > 1 else [])
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in all_streams] for _ in range(R + 1)]
+    t0 = time.perf_counter()
+    state["timed"] = True
+    for e, s_ in zip(marks[0], all_streams):
+        e.record(s_)
+    for r in range(R):
+        for i in range(args.steps):
+            step(r * args.steps + i)
+        flush()
+        for e, s_ in zip(marks[r + 1], all_streams):
+            e.record(s_)
     state["timed"] = False
     torch.cuda.synchronize()
     if N > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_region = time.perf_counter() - t0
+    # boundary r = the moment the LAST stream passed its mark (the streams start idle and together: marks[0] are equal within
+    # the time it takes to record them)
+    bounds = [max(marks[0][0].elapsed_time(e) for e in marks[r]) for r in range(R + 1)]
+    # Short passes (the driver's --steps 20 = 0.85 ms) do not end on the same stream each time (20 steps over 3 streams), so single
+    # passes alternate between two lengths; the median is taken over GROUPS of consecutive passes of >= 20 ms each (at least 3
+    # groups, at most 15): per-step time of a group = its span / its steps.
+    per_group = max(1, min(R // 3 if R >= 3 else 1, int(-(-20.0 // max(probe_ms, 1e-3)))))
+    n_groups = R // per_group
+    grp_ms = sorted((bounds[(g + 1) * per_group] - bounds[g * per_group]) / per_group for g in range(n_groups))
+    rep_ms = sorted(bounds[r + 1] - bounds[r] for r in range(R))
+    if n_groups >= 3:
+        dt = grp_ms[n_groups // 2] * 1e-3             # the median group, as the time of ONE pass of --steps steps
+    else:
+        dt = dt_region / R                            # too few passes for a median: the region's own mean
     if N > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt, dt_region], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_region = float(t[0].item()), float(t[1].item())
+    total_steps = R * args.steps
+    timing = {"repetitions": R, "steps_per_repetition": args.steps, "timed_region_ms": dt_region * 1e3,
+              "ms_per_step_region_mean": dt_region / total_steps * 1e3,
+              "ms_per_step_median_group": dt / args.steps * 1e3,
+              "passes_per_group": per_group, "groups": n_groups,
+              "ms_per_step_min_group": grp_ms[0] / args.steps, "ms_per_step_max_group": grp_ms[-1] / args.steps,
+              "ms_per_step_min_rep": rep_ms[0] / args.steps, "ms_per_step_max_rep": rep_ms[-1] / args.steps,
+              "how": "one timed region (barrier + synchronize on both sides) of `repetitions` back-to-back passes of `steps` steps; "
+                     "HIP events on every launch stream mark the pass boundaries; ms_per_step = median over groups of consecutive passes "
+                     "(>= 20 ms each) of group span / group steps" + ("" if n_groups >= 3 else " (fewer than 3 groups: the region's mean)")}
 
     # the frames the TIMED steps produced are checked too: every buffer still in flight at the end
     ok = True
     if N > 1:
         # the assembled frame must equal a whole-frame render of this rank (which passed the gate above)
-        last = (args.steps - 1) % B
+        last = (total_steps - 1) % B
         if args.gather:
             ok = all(bool((gate == g).all().item()) for g in gfinals[last]) if rank == 0 else True
         else:
@@ -373,7 +429,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
     else:
-        for b in range(min(B, args.steps + args.warmup)):
+        for b in range(min(B, total_steps + args.warmup)):
             ok = ok and bool((gate == frames[b][0]).all().item())
     frame_check["timed_frames_match"] = ok
     if not ok:
@@ -402,7 +458,7 @@ def main():
     torch.cuda.synchronize()
 
     if rank == 0:
-        frames_done = args.steps * N
+        frames_done = args.steps * N                    # per pass of --steps; dt is the median pass
         total_rays = rays_per_frame * frames_done
         value = total_rays / dt / 1e6
         cpu = None
@@ -416,30 +472,61 @@ def main():
                     print(json.dumps({"error": "rendered rows differ from the oracle", "workload": args.workload}), flush=True)
                     raise SystemExit(2)
         # Which roofline: the path is scalar-per-ray fp32 VALU work -> the VECTOR ALU is the primary
-        # bound.  achieved = algorithmic fp32 operations per launch (SURVEY 8(d) weights, counted by the oracle:
-        # tests/golden/work.json, div and sqrt = 1) / the kernel's mean launch duration measured here with HIP events;
-        # peak = the FMA-counting fp32 vector peak (bit-exactness forbids contraction, so half of it is the most
-        # un-fused arithmetic can reach).
-        work = algorithmic_work(snap)
-        flops, flops_src = None, None
-        if work is not None and work["rays"] == rays_per_frame:
-            flops, flops_src = work["flops"], work.get("source", "oracle count of the whole frame") + ", tests/golden/work.json"
+        # bound; peak = the FMA-counting fp32 vector peak (bit-exactness forbids contraction, so half of it is the most
+        # un-fused arithmetic can reach).  TWO counts of the algorithmic fp32 operations of a frame exist, both with the
+        # weights of SURVEY 8(d) (div and sqrt = 1), and EVERY workload's line carries both with both fractions:
+        #   flops_oracle  the reference's algorithm as the CPU restatement executes it: every element of every list
+        #                 walked, no cull (tests/golden/work.json "deferred"; for a scene the oracle cannot walk whole --
+        #                 config 5 -- its count on a band of rows scaled by rays: "oracle_band", or this run's cpu_baseline band)
+        #   flops_kernel  the same weights added by every lane of the kernel for each step it actually executes
+        #                 (QR_PROF build, tools/gpu_work.py: work.json "kernel"); the culls' own arithmetic is not in it
+        # `achieved` / `frac` use the oracle's count (SURVEY 8(d) defines the figure by the CPU restatement's counters) and
+        # `basis` says so; achieved_kernel / frac_kernel stand beside them.  Both over the kernel's mean launch duration
+        # measured here with HIP events.
+        work_all = all_work(snap)
+        flops_oracle, oracle_src, flops_kernel, kernel_src = None, None, None, None
+        d = work_all.get("deferred")
+        if d is not None and d.get("rays") == rays_per_frame and "kernel-side" not in d.get("source", ""):
+            flops_oracle, oracle_src = d["flops"], "oracle count of the whole frame, tests/golden/work.json"
         elif cpu is not None and cpu.get("band"):
-            flops = int(cpu["band"]["flops"] / max(1, cpu["band"]["rays"]) * rays_per_frame)
-            flops_src = "oracle count on the cpu_baseline band, scaled by rays"
+            flops_oracle = int(cpu["band"]["flops"] / max(1, cpu["band"]["rays"]) * rays_per_frame)
+            oracle_src = (f"oracle count on rows {cpu['band']['rows'][0]}..{cpu['band']['rows'][1]} of this run's cpu_baseline, scaled by rays "
+                          "(the oracle walks the LISTS of this scene; the kernel walks grids)")
+        elif work_all.get("oracle_band") is not None:
+            ob = work_all["oracle_band"]
+            flops_oracle = int(ob["flops"] / max(1, ob["rays"]) * rays_per_frame)
+            oracle_src = f"oracle count on rows {ob['rows'][0]}..{ob['rows'][1]} (tests/golden/work.json oracle_band), scaled by rays"
+        k = work_all.get("kernel")
+        if k is not None and k.get("rays") == rays_per_frame:
+            flops_kernel, kernel_src = k["flops"], k.get("source", "kernel-side count") + ", tests/golden/work.json"
         counters = committed_counters(args.workload)
         if counters is not None and counters.get("stale"):
             roofline_stale, counters = counters, None
         else:
             roofline_stale = None
         roofline = dict(bound="valu", achieved=None, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=None,
+                        basis="flops_oracle" if flops_oracle is not None else ("flops_kernel" if flops_kernel is not None else None),
                         traffic=(counters or {}).get("hbm_bytes_per_launch"),
-                        kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms)
+                        kernel=qr.lib().qr_kernel_name().decode(), kernel_avg_ms=avg_ms, kernel_min_ms=min_ms,
+                        flops_oracle=flops_oracle, flops_oracle_source=oracle_src,
+                        flops_kernel=flops_kernel, flops_kernel_source=kernel_src)
         if roofline_stale is not None:
             roofline["counters"] = roofline_stale
+        for name, fl in (("oracle", flops_oracle), ("kernel", flops_kernel)):
+            if fl is not None:
+                tf = fl / (avg_ms * 1e-3) / 1e12
+                roofline[f"achieved_{name}"] = tf
+                roofline[f"frac_{name}"] = tf / VALU_PEAK_TFLOPS
+        flops = flops_oracle if flops_oracle is not None else flops_kernel
         if flops is not None:
             tf = flops / (avg_ms * 1e-3) / 1e12
-            roofline.update(achieved=tf, frac=tf / VALU_PEAK_TFLOPS, flops_per_launch=flops, flops_source=flops_src)
+            roofline.update(achieved=tf, frac=tf / VALU_PEAK_TFLOPS, flops_per_launch=flops)
+        if counters is not None and counters.get("thread_cycles_valu") and flops_kernel:
+            # how many vector lane-operations the kernel issues per algorithmic operation it executes (SQ_THREAD_CYCLES_VALU of
+            # the committed counter pass of this build / flops_kernel): the overhead factor of the implementation
+            roofline["valu_lane_ops_per_flop"] = counters["thread_cycles_valu"] / flops_kernel
+            if flops_oracle:
+                roofline["valu_lane_ops_per_flop_oracle"] = counters["thread_cycles_valu"] / flops_oracle
         # the HBM leg, for the record (deliberate correction of SURVEY 8(d): the kernel reads the scene through the
         # scalar cache, not once per workgroup, so the algorithmic bytes are one frame write + one scene read)
         alg_bytes = 4 * W * H + int(scn.info.device_bytes)
@@ -456,7 +543,7 @@ def main():
             if insts > 0:
                 peak = 0.93 * 1024
                 per_launch = insts / (avg_ms * 1e-3) / 1e9
-                per_frame = insts * args.steps / dt / 1e9       # one frame's worth of instructions per GPU and step
+                per_frame = insts * args.steps / dt / 1e9       # one frame's worth of instructions per GPU and step (median pass)
                 roofline["issue"] = dict(unit="G wave-instructions/s", peak=peak, wave_instructions_per_launch=insts,
                                          achieved_isolated_launch=per_launch, frac_isolated_launch=per_launch / peak,
                                          achieved_in_flight=per_frame, frac_in_flight=per_frame / peak,
@@ -475,6 +562,7 @@ def main():
                        "parallelism": f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps" if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
                        "frame_check": frame_check, "assembled_frame_matches": ok},
+            "timing": timing,
             "lib": qr.lib().qr_version().decode(),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -1481,25 +1481,36 @@ int qr_program_verify(const QrProgram &p, std::string &err)
         }
         return nullptr;
     };
+    static const bool vt = getenv("QR_VERIFY_TIMING") != nullptr;
+    struct timespec vt0; if (vt) clock_gettime(CLOCK_MONOTONIC, &vt0);
+    auto vtick = [&](const char *what) { if (!vt) return; struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "  verify %-8s %.3f ms\n", what, (t1.tv_sec - vt0.tv_sec) * 1e3 + (t1.tv_nsec - vt0.tv_nsec) * 1e-6); vt0 = t1; };
     const DevHeader *h = (const DevHeader *)b.data();
     if (h->off_tiles != p.off_tiles || h->off_order != p.off_order || h->off_shade != p.off_shade) return bad("header offsets");
     if ((size_t)p.off_tiles + (size_t)p.n_tiles * 4 > limit) return bad("tile array");
     const uint32_t *tl = (const uint32_t *)(b.data() + p.off_tiles);
-    for (uint32_t i = 0; i < p.n_tiles; i++) if (const char *m = check_list(tl[i])) return bad(m);
+    /* neighbouring tiles mostly share one program (lists are stored once per content): a head equal to the one just checked
+     * needs no second look */
+    { uint32_t prev = 0; for (uint32_t i = 0; i < p.n_tiles; i++) { if (tl[i] == prev) continue; if (const char *m = check_list(tl[i])) return bad(m); prev = tl[i]; } }
+    vtick("tiles");
     if ((size_t)p.off_order + (size_t)p.n_sched * 8 > limit) return bad("schedule");
     const uint32_t *ord = (const uint32_t *)(b.data() + p.off_order);
     const int fw = p.frm.fsaa == 2 ? 4 : 8, fh = p.frm.fsaa == 0 ? 8 : 4;
+    const uint32_t max_bx = (uint32_t)((p.frm.frm_w + fw - 1) / fw), max_by = (uint32_t)((p.frm.frm_h + fh - 1) / fh);
+    uint32_t prev_hd = 0;
     for (uint32_t i = 0; i < p.n_sched; i++)
     {
         const uint32_t e = ord[2 * i], hd = ord[2 * i + 1];
-        if ((int)(e & 0x3FFFu) * fw >= p.frm.frm_w || (int)((e >> 14) & 0x3FFFu) * fh >= p.frm.frm_h) return bad("schedule footprint outside the frame");
+        if ((e & 0x3FFFu) >= max_bx || ((e >> 14) & 0x3FFFu) >= max_by) return bad("schedule footprint outside the frame");
+        if (hd == prev_hd && hd >= 256u) continue;
         if (hd < 256u)
         {
             /* a run of hd empty footprints along the row (0: one) */
             if (hd > QR_CLEAR_RUN_MAX || ((int)(e & 0x3FFFu) + (int)(hd ? hd : 1u) - 1) * fw >= p.frm.frm_w) return bad("clear run leaves the frame");
         }
-        else if (hd != QR_SCHED_PER_LANE) if (const char *m = check_list(hd)) return bad(m);
+        else if (hd != QR_SCHED_PER_LANE) { if (const char *m = check_list(hd)) return bad(m); prev_hd = hd; }
     }
+    vtick("sched");
     for (uint32_t i = 0; i <= p.n_srf; i++)
     {
         const DSurf *d = (const DSurf *)(b.data() + p.off_srf) + i;
@@ -1567,6 +1578,7 @@ int qr_program_verify(const QrProgram &p, std::string &err)
         }
         if (s->srf != p.off_srf + i * (uint32_t)sizeof(DSurf)) return bad("shade record surface offset");
     }
+    vtick("surfaces");
     for (uint32_t i = 0; i <= p.n_mat; i++)
     {
         const qr_material *m = (const qr_material *)(b.data() + p.off_mat) + i;

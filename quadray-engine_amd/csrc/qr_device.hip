@@ -20,6 +20,7 @@
 #include <thread>
 #include <mutex>
 #include <map>
+#include <atomic>
 #include <array>
 #include <algorithm>
 #include <chrono>
@@ -35,6 +36,8 @@
 
 struct qr_device_scene
 {
+    uint64_t serial = 0;        /* unique per upload for the life of the process: caches keyed on a scene (the QR_DEVICES replicas of
+                                 * qr_render_host) use it -- a destroyed scene's address and its image's device address are reused */
     int device = 0;
     void *d_blob = nullptr;     /* the compiled scene image (qr_program.h), one allocation */
     uint64_t blob_bytes = 0;
@@ -172,6 +175,8 @@ extern "C" int qr_scene_upload_ex(const void *blob, uint64_t size, int device, u
     memcpy(stage.p, prog.blob.data(), total);
 
     qr_device_scene *s = new qr_device_scene();     /* value-initialised: plain members are zero */
+    static std::atomic<uint64_t> next_serial{1};
+    s->serial = next_serial.fetch_add(1, std::memory_order_relaxed);
     s->device = device;
     s->hdr = hdr;
     const double tm0 = now_ms();
@@ -622,6 +627,21 @@ extern "C" int qr_render_timed(qr_device_scene *s, void *frame_dev, void *stream
     return QR_OK;
 }
 
+#ifdef QR_WAVETIME
+/* QR_WAVETIME builds only (tools/gpu_timeline.py): the stamps the waves of this scene's LAST launch wrote, QR_WT_SLOTS words per
+ * schedule entry; not part of include/qrhip.h -- the product library does not export it */
+extern "C" int qr_wavetime_read(qr_device_scene *s, unsigned long long *out, uint64_t n_words, int clear)
+{
+    if (s == nullptr || out == nullptr) return qr_fail(QR_ERR_ARG, "bad argument");
+    const uint64_t have = (uint64_t)s->lp.n_blocks * QR_WT_SLOTS;
+    if (n_words > have) n_words = have;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(out, s->d_counters + 64, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (clear) HIP_TRY(hipMemset(s->d_counters + 64, 0, have * sizeof(unsigned long long)));
+    return (int)QR_WT_SLOTS;
+}
+#endif
+
 /* per-thread device frame + pinned staging buffer, kept between calls: the drop-in path renders a frame
  * per call, and hipMalloc/hipFree plus a pageable 8 MB copy cost more than the kernel itself */
 #define QR_COPY_CHUNKS 4
@@ -659,9 +679,9 @@ static void copy_streaming(void *dst, const void *src, size_t n)
  * them in place -- here a device owns a band).  The same ordinal may be listed more than once (separate buffers and
  * streams on that device: how a one-GPU box tests the path).  Without QR_DEVICES: the one device of QR_DEVICE (default 0).
  */
-static std::vector<int> device_list()
+static int device_list(std::vector<int> &v)
 {
-    std::vector<int> v;
+    v.clear();
     if (const char *e = getenv("QR_DEVICES"))
     {
         const char *p = e;
@@ -671,14 +691,16 @@ static std::vector<int> device_list()
             if (!*p) break;
             char *end = nullptr;
             const long d = strtol(p, &end, 10);
-            if (end == p) break;
+            if (end == p) return qr_fail(QR_ERR_ARG, std::string("QR_DEVICES: not a list of device ordinals: ") + e);
+            /* without any device the call fails as QR_ERR_DEVICE further down (pick_device): no CPU fallback */
+            if (d < 0 || (qr_device_count() > 0 && d >= qr_device_count())) return qr_fail(QR_ERR_ARG, std::string("QR_DEVICES: ordinal out of range in ") + e);
+            if (v.size() >= QR_MAX_DEVICES) return qr_fail(QR_ERR_ARG, std::string("QR_DEVICES: more than ") + std::to_string(QR_MAX_DEVICES) + " entries");
             v.push_back((int)d);
             p = end;
         }
     }
     if (v.empty()) { int d = 0; if (const char *e = getenv("QR_DEVICE")) d = atoi(e); v.push_back(d); }
-    if (v.size() > QR_MAX_DEVICES) v.resize(QR_MAX_DEVICES);
-    return v;
+    return QR_OK;
 }
 
 /*
@@ -694,7 +716,10 @@ static std::mutex g_pins_lock;
 extern "C" int qr_frame_register(void *frame, uint64_t bytes)
 {
     if (frame == nullptr || bytes == 0) return qr_fail(QR_ERR_ARG, "null frame");
-    const int rc = pick_device(device_list()[0]);
+    std::vector<int> dl;
+    int rc = device_list(dl);
+    if (rc != QR_OK) return rc;
+    rc = pick_device(dl[0]);
     if (rc != QR_OK) return rc;
     std::lock_guard<std::mutex> lk(g_pins_lock);
     for (const PinnedRange &r : g_pins)
@@ -782,7 +807,7 @@ struct HostPathCache
     uint32_t *h_frame = nullptr; size_t h_cap = 0;
     hipEvent_t ev[QR_COPY_CHUNKS] = {};
     /* QR_DEVICES with several entries: replicas of the scene this thread rendered last */
-    const qr_device_scene *rep_scene = nullptr; uint64_t rep_bytes = 0; const void *rep_blob = nullptr;
+    uint64_t rep_serial = 0;      /* qr_device_scene::serial the replicas were built for (0: none) */
     std::vector<int> rep_devices;
     std::vector<HostReplica> rep;
     ~HostPathCache()
@@ -803,7 +828,7 @@ static void replicas_release(HostPathCache &c)
         if (r.st) (void)hipStreamDestroy(r.st);
         if (r.ev) (void)hipEventDestroy(r.ev);
     }
-    c.rep.clear(); c.rep_scene = nullptr; c.rep_blob = nullptr; c.rep_bytes = 0; c.rep_devices.clear();
+    c.rep.clear(); c.rep_serial = 0; c.rep_devices.clear();
 }
 
 /* the kernel instance an uploaded scene renders with, for an explicit schedule / image / counter block */
@@ -820,7 +845,9 @@ static hipError_t launch_instance(const qr_device_scene *s, const LaunchP &lp, u
  * of every band, a frame buffer, a stream */
 static int replicas_prepare(HostPathCache &c, qr_device_scene *s, const std::vector<int> &devs)
 {
-    if (c.rep_scene == s && c.rep_blob == s->d_blob && c.rep_bytes == s->blob_bytes && c.rep_devices == devs) return QR_OK;
+    /* keyed on the upload's serial: the address of a destroyed scene and of its image are reused by the next upload of the
+     * same size (an animation re-uploads every frame), and replicas of the old image must not render for the new one */
+    if (c.rep_serial == s->serial && c.rep_devices == devs) return QR_OK;
     replicas_release(c);
     const int n = (int)devs.size(), H = s->fr.frm_h, W = s->fr.frm_w;
     const int fh = s->fr.fsaa == 0 ? 8 : 4;
@@ -858,7 +885,7 @@ static int replicas_prepare(HostPathCache &c, qr_device_scene *s, const std::vec
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r.ev, hipEventDisableTiming);
         if (e != hipSuccess) { replicas_release(c); return qr_fail(QR_ERR_DEVICE, std::string("QR_DEVICES replica: ") + hipGetErrorString(e)); }
     }
-    c.rep_scene = s; c.rep_blob = s->d_blob; c.rep_bytes = s->blob_bytes; c.rep_devices = devs;
+    c.rep_serial = s->serial; c.rep_devices = devs;
     return QR_OK;
 }
 
@@ -882,7 +909,8 @@ extern "C" int qr_render_host(qr_device_scene *s, uint32_t *frame_host, int row_
     }
 
     /* ---- several devices: one band of rows each ---- */
-    const std::vector<int> devs = getenv("QR_DEVICES") ? device_list() : std::vector<int>();
+    std::vector<int> devs;
+    if (getenv("QR_DEVICES")) { const int rc = device_list(devs); if (rc != QR_OK) return rc; }
     if (devs.size() > 1 && whole && !s->pt_on)
     {
         int rc = replicas_prepare(c, s, devs);
@@ -1023,7 +1051,6 @@ struct DropIn
     QrProgram prog;
     bool compiled = false;              /* prog is the program of last_blob ... */
     int compiled_blocks = 0;            /* ... with its schedule grouped for this many row blocks */
-    QrProgramStats verified = {}; int verified_blocks = 0;     /* layout of the last image qr_program_verify walked */
 };
 static thread_local DropIn g_drop;
 
@@ -1219,7 +1246,9 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
     /* the devices of this call, and with them the number of row blocks of the schedule: QR_DROPIN_BLOCKS on one device,
      * a run of blocks (at least one) for each of several.  A path-traced frame stays on the first device: its sample planes
      * live there */
-    std::vector<int> devs = device_list();
+    std::vector<int> devs;
+    rc = device_list(devs);
+    if (rc != QR_OK) return rc;
     qr_scene_view v;
     rc = qr_scene_view_init(&v, c.blob.data(), c.blob.size());
     if (rc != 0) return qr_fail(QR_ERR_ARG, "malformed snapshot (qr_scene_view_init " + std::to_string(rc) + ")");
@@ -1256,21 +1285,17 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
             rc = rebin_tiles(v, bsph, frm, E, T);
             if (rc != QR_OK) return rc;
         }
-        /* the finished image is verified offset by offset (qr_program_verify, a third of the compile time at 1080p) when its
-         * structure differs from the last image this thread verified -- the first frame, and whenever lists or cells come
-         * or go; an animation that only moves things yields the same layout from the same code path.  QR_VERIFY=1: always,
-         * 0: never */
-        static const int verify_env = []() { const char *e = getenv("QR_VERIFY"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        /* the finished image is verified offset by offset (qr_program_verify) on EVERY frame that was compiled: the layout
+         * depends on list contents (programs shared by content, clear runs, box cells), so equal totals do not mean an equal
+         * structure, and the product kernel checks no offset it loads.  The walk costs ~0.05 ms at 1080p since heads equal to
+         * the one just checked are skipped (tools/host_compile_time.py).  QR_VERIFY=0 switches it off (timing experiments) */
+        static const bool verify_on = []() { const char *e = getenv("QR_VERIFY"); return e == nullptr || atoi(e) != 0; }();
         rc = qr_program_build(v, E, T, frm, bsph, c.prog, err, want_blocks, false);
         if (rc != QR_OK) return qr_fail(rc, err);
-        const QrProgramStats &ps = c.prog.stats;
-        const bool changed = ps.bytes != c.verified.bytes || ps.n_lists != c.verified.n_lists || ps.n_cells != c.verified.n_cells
-                          || ps.n_clip_cells != c.verified.n_clip_cells || ps.n_dropped != c.verified.n_dropped || c.verified_blocks != want_blocks;
-        if (verify_env == 1 || (verify_env < 0 && changed))
+        if (verify_on)
         {
             rc = qr_program_verify(c.prog, err);
             if (rc != QR_OK) return qr_fail(rc, err);
-            c.verified = ps; c.verified_blocks = want_blocks;
         }
     }
     const double t2 = now_ms();
@@ -1320,6 +1345,10 @@ extern "C" int qr_render0(const void *s_inf, const qr_abi_desc *abi)
         HIP_TRY(hipSetDevice(c.slot[0].device));
         rc = dropin_pt_begin(c.slot[0], s_inf, abi, fr, ptio, pt);
         if (rc != QR_OK) return rc;
+        /* the seed and colour planes travel on the slot's first stream AFTER the image: the launch streams of the later row
+         * blocks wait on ev_up, so it is recorded again behind those copies (round 4: recorded only behind the image, a block
+         * on sx[1] / sx[2] could start before its seeds had arrived -- one wrong frame in ~20 runs with four engine threads) */
+        HIP_TRY(hipEventRecord(c.slot[0].ev_up, c.slot[0].sk));
     }
     else
     {

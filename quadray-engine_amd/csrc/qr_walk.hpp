@@ -659,7 +659,7 @@ __device__ __forceinline__ void solve_cell(BaseP B, u32 op, u32 srf_off, const S
  * SHADOW: any-hit walk, ends as soon as every ray is occluded.
  */
 #ifndef QR_ASM_CULL
-#define QR_ASM_CULL 1       /* 0: the run of culled cells as compiled C++ (the statistics / guard builds always use that form) */
+#define QR_ASM_CULL 1       /* 0: the run of culled cells as compiled C++ (the statistics / profile builds always use that form; the guard build keeps the assembly: QR_GUARD_ASM) */
 #endif
 
 /*
@@ -855,8 +855,13 @@ __device__ __forceinline__ void walk_list(BaseP B, u32 head, const Ray &r, Hit &
          * the walk's only cell load.
          */
         u32x8 c;
-#if QR_ASM_CULL && !defined(QR_STATS) && !defined(QR_PROF) && !defined(QR_WAVETIME) && !defined(QR_GUARD)
+#if QR_ASM_CULL && ((!defined(QR_STATS) && !defined(QR_PROF) && !defined(QR_WAVETIME) && !defined(QR_GUARD)) || defined(QR_GUARD_ASM))
+        /* QR_GUARD_ASM (the guard library of the GPU suite): the hand-written loop stays -- the guarded walk runs the product's
+         * instructions -- and the cursor is checked before the run loads its first cell and when it hands a cell out (the
+         * statistics of culled cells are not kept in that build) */
+        QR_GUARD_POS(1, pos, head, return);
         cull_run<BOXC>(B, pos, c, r, w, idx, idy, idz, nox, noy, noz, dd, dde, dlen);
+        QR_GUARD_POS(4, pos, head, return);
 #else
         for (;;)
         {

@@ -106,3 +106,50 @@ def test_gpu_drop_in_over_a_device_list_and_a_registered_frame(env, extra):
         assert f"{n} device slot" in out.stderr, out.stderr[-2000:]
         if extra:
             assert "registered frame: direct" in out.stderr, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_gpu_replicas_do_not_outlive_their_scene(qr, monkeypatch):
+    """An animation uploads a scene of the same size every frame: the destroyed scene's address and its image's device
+    address are reused by the next upload, so the per-thread QR_DEVICES replicas are keyed on the upload's serial, not on
+    pointers and sizes.  Upload A, render over a device list, destroy A, upload B of the same size (A with the camera moved:
+    same records and lists, another picture; expected frame from the oracle), render: B's frame, not A's."""
+    import struct
+    import qr_oracle
+    a = load_blob("demo01_160")
+    off_frame = struct.unpack_from("<I", a, 40)[0]                   # qr_header.off_frame (include/qr_scene.h)
+    org = list(struct.unpack_from("<3f", a, off_frame + 25 * 4))     # qr_frame.org
+    b = bytearray(a)
+    struct.pack_into("<3f", b, off_frame + 25 * 4, org[0] + 0.75, org[1] - 0.5, org[2] + 0.25)
+    b = bytes(b)
+    want_a = load_frame("demo01_160") & 0xFFFFFF
+    want_b = qr_oracle.render(b, threads=4)[0] & 0xFFFFFF
+    assert (want_a != want_b).sum() > 1000
+    monkeypatch.setenv("QR_DEVICES", "0,0")
+    same_address = 0
+    for _ in range(4):
+        sa = qr.Scene(a)
+        ha = sa._h.value
+        assert (sa.render_host() == want_a).all()
+        sa.close()
+        sb = qr.Scene(b)
+        same_address += sb._h.value == ha
+        got = sb.render_host()
+        assert (got == want_b).all(), f"stale replicas: {(got != want_b).sum()} pixels differ (handle address reused: {sb._h.value == ha})"
+        sb.close()
+    print(f"scene handle address reused in {same_address} of 4 rounds")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,7", "0,-1", "0,x", "0,0,0,0,0,0,0,0,0"])
+def test_gpu_bad_device_lists_are_refused(qr, monkeypatch, devices):
+    """QR_DEVICES: an ordinal the box does not have, a negative one, garbage, more than QR_MAX_DEVICES entries: QR_ERR_ARG,
+    not a silently shortened or truncated list (a one-GPU box has ordinal 0 only)."""
+    scn = qr.Scene(load_blob("demo01_160"))
+    monkeypatch.setenv("QR_DEVICES", devices)
+    if qr.lib().qr_device_count() > 7 and devices == "0,7":
+        pytest.skip("ordinal 7 exists on this box")
+    with pytest.raises(qr.QrError):
+        scn.render_host()
+    monkeypatch.delenv("QR_DEVICES")
+    assert (scn.render_host() == (load_frame("demo01_160") & 0xFFFFFF)).all()

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_ab.sh LIB_A LIB_B [workloads...]  -- alternating runs of two builds of libqrhip (QR_LIB), same box, same call
+python3 ${GRAFT_REPO_ROOT:-$PWD}/tools/archive_src.py >/dev/null 2>&1 || true
 A=$1; B=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$PWD}
 for w in "${@:-demo1_1080p}"; do

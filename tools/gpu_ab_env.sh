@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_ab_env.sh "ENV_A" "ENV_B" [workloads...]  -- alternating bench runs of the product build under two
 # environments (e.g. "QR_LIST_DEDUP=0" "QR_LIST_DEDUP=1"), same box, same call
+python3 ${GRAFT_REPO_ROOT:-$PWD}/tools/archive_src.py >/dev/null 2>&1 || true
 A=$1; B=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$PWD}
 for w in "${@:-demo1_1080p}"; do

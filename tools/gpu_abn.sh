@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_abn.sh WORKLOAD LIB...  -- alternating bench runs of several builds of libqrhip (QR_LIB), same box, same call
+python3 ${GRAFT_REPO_ROOT:-$PWD}/tools/archive_src.py >/dev/null 2>&1 || true
 W=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 for rep in 1 2; do

@@ -2,6 +2,7 @@
 # Drop-in fuzz on the GPU box: the unmodified engine renders random scenes with its own CPU backend and through
 # qr_render0 (oracle/_ref/qr_ref_shim --gpu compares the two frames): transforms fuzzed inside the engine (--jitter)
 # and swarms of extra quadrics (--swarm).  usage: tools/gpu_dropin_fuzz.sh [seeds]  -> one line per scene + a summary
+python3 ${GRAFT_REPO_ROOT:-$PWD}/tools/archive_src.py >/dev/null 2>&1 || true
 R=${GRAFT_REPO_ROOT:-$PWD}
 N=${1:-10}
 T=$(mktemp -d); mkdir -p $T/dump; cd $T

@@ -1,5 +1,5 @@
 import os, sys, gzip
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from qr_loader import load_package

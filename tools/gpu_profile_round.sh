@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/gpu_profile_round.sh TAG  -> gpurun_out/TAG_*  (bench lines, kernel traces, PMC passes)
 # then, in the build container: python tools/make_profiles.py TAG rNN  (writes profiles/rNN_* and profiles/counters.json)
+python3 ${GRAFT_REPO_ROOT:-$PWD}/tools/archive_src.py >/dev/null 2>&1 || true
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out

@@ -84,6 +84,7 @@ for w in ("demo1_1080p", "demo1_1080p_d0", "demo2_1080p_gf_d3", "demo2_2160p_aa4
     e = dict(insts_valu=cc["SQ_INSTS_VALU"], insts_salu=cc["SQ_INSTS_SALU"], insts_smem=cc["SQ_INSTS_SMEM"],
              insts_vmem_rd=cc.get("SQ_INSTS_VMEM_RD"), insts_vmem_wr=cc.get("SQ_INSTS_VMEM_WR"),
              waves=cc.get("SQ_WAVES"), wave_cycles=cc.get("SQ_WAVE_CYCLES"),
+             thread_cycles_valu=cc.get("SQ_THREAD_CYCLES_VALU"),
              lane_utilisation=cc["SQ_THREAD_CYCLES_VALU"] / (64 * cc["SQ_INSTS_VALU"]) if cc.get("SQ_THREAD_CYCLES_VALU") else None,
              source=f"profiles/{rnd}_counters_all_workloads.txt (rocprofv3 --pmc passes of tools/gpu_profile_round.sh)", git=git, lib=lib)
     if "FETCH_SIZE" in cc and "WRITE_SIZE" in cc:
