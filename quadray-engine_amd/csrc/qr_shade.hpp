@@ -82,6 +82,111 @@ __device__ __forceinline__ float pt_cos(float x)
     return d;
 }
 
+/* LT_amb .. LT_end for one light that reaches the hit, tracer.cpp:2879-3156: attenuated diffuse term, specular term raised to
+ * the material's 28.4 fixed-point power, metal / plain colour blend, added to `col` */
+__device__ __forceinline__ void light_terms(const char *__restrict__ G, u32 mo, int props, const qr_light *__restrict__ lg,
+                                            const V3 &L, float dot, const Ray &r, const V3 &nrm, const V3 &tex, V3 &col)
+{
+    const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
+    float x0, x1, x2, x3, x4, x5, x6, x7;
+    x1 = L.x; x4 = x1 * x1;
+    x2 = L.y; x5 = x2 * x2;
+    x3 = L.z; x6 = x3 * x3;
+    x4 = x4 + x5; x4 = x4 + x6;
+    const float r2 = x4;
+    x0 = dot;
+    QR_FLOPS(10);
+    if (props & QR_PROP_DIFFUSE)
+    {
+        QR_FLOPS(17);
+        x6 = x4;
+        x5 = rsq(x4);
+        x4 = x5 * x6;
+        x6 = x6 * lg->a_qdr;
+        x4 = x4 * lg->a_lnr;
+        x6 = x6 + lg->a_cnt;
+        x6 = x6 + x4;
+        x4 = rsq(x6);
+        x6 = x0;
+        x0 = x0 * x4;
+        x0 = x0 * x5;
+        x0 = x0 * mt->l_dff;
+    }
+    else
+    {
+        x6 = x0;
+        x0 = 0.0f;
+    }
+    bool plain = false;
+    float spec = 0.0f;
+    if (props & QR_PROP_SPECULAR)
+    {
+        x4 = x6; x5 = x6;
+        x4 = x4 * nrm.x; x1 = x1 - x4; x1 = x1 - x4;
+        x5 = x5 * nrm.y; x2 = x2 - x5; x2 = x2 - x5;
+        x6 = x6 * nrm.z; x3 = x3 - x6; x3 = x3 - x6;
+        x4 = r.dir.x; x1 = x1 * x4; x4 = x4 * x4;
+        x5 = r.dir.y; x2 = x2 * x5; x5 = x5 * x5;
+        x6 = r.dir.z; x3 = x3 * x6; x6 = x6 * x6;
+        x6 = x6 + x4; x6 = x6 + x5;
+        x1 = x1 + x2; x1 = x1 + x3;
+        if (clt(0.0f, x1))
+        {
+            QR_FLOPS(32);
+            x4 = r2;
+            x5 = rsq(x6); x1 = x1 * x5;
+            x5 = rsq(x4); x1 = x1 * x5;
+            /* fixed-point 28.4 power, 2981-3039 */
+            const u32 lpow = mt->l_pow;
+            u32 pw = lpow & 0xF;
+            x2 = x1; x4 = x1; x1 = 1.0f;
+            while (pw != 0)
+            {
+                x4 = __builtin_sqrtf(x4);
+                const u32 bit = pw & 0x8;
+                pw = (pw << 1) & 0xF;
+                if (bit) x1 = x1 * x4;
+            }
+            pw = lpow >> 4;
+            if (pw != 0)
+            {
+                x3 = x1; x1 = 1.0f;
+                do
+                {
+                    const u32 bit = pw & 1;
+                    pw >>= 1;
+                    if (bit) x1 = x1 * x2;
+                    x2 = x2 * x2;
+                }
+                while (pw != 0);
+                x1 = x1 * x3;
+            }
+            x1 = x1 * mt->l_spc;
+            if (props & QR_PROP_METAL) { x0 = x0 + x1; }
+            else { plain = true; spec = x1; }
+        }
+    }
+    if (!plain)
+    {
+        x1 = tex.x * lg->col[0];
+        x2 = tex.y * lg->col[1];
+        x3 = tex.z * lg->col[2];
+        x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+        col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+    }
+    else
+    {
+        x7 = spec;
+        x1 = tex.x; x2 = tex.y; x3 = tex.z;
+        x4 = lg->col[0]; x5 = lg->col[1]; x6 = lg->col[2];
+        x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
+        x1 = x1 * x4; x2 = x2 * x5; x3 = x3 * x6;
+        x4 = x4 * x7; x5 = x5 * x7; x6 = x6 * x7;
+        x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
+        col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
+    }
+}
+
 struct Counters { u32 primary, shadow, reflect, refract; };
 
 /* state of the enclosing recursion that only has to survive a shade() call */
@@ -276,6 +381,136 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
 
     QR_PROF_HIT(24);                    /* shade() calls */
     if (pt_stage != 2 && pt_stage != 3) QR_FLOPS_M(16 + 4 + 6, __popcll(__ballot(act)));            /* normal, texture look-up, ambient */
+    /*
+     * Shadow rays of SECONDARY hits, regrouped over the lanes of the wave (DIVK instance, rounds that are not all primary
+     * rays).  The loop below walks the lights one position at a time and sends each light's shadow rays through the
+     * traversal alone -- on the 10 000-object scene 20 of 64 lanes at the start of such a walk (half of a round's 30 hits
+     * face a given light), 9.6 stepping on average, four walks per round.  Here the shadow rays of up to four light
+     * positions of ALL hits of the round -- (hit, light) pairs -- are queued in LDS and dealt out to the lanes 64 at a time:
+     * a lane traces a ray of ANOTHER lane's hit (the hit from its owner's registers through ds_bpermute, the light from its
+     * list entry) and reports occlusion in a bit of the owner's LDS word.  The owner then adds its lights' terms in list
+     * order with the arithmetic of the loop below, so colours keep every bit (tests: all synthetic-scene parity tests).
+     */
+    if constexpr (DIVK && !PT)
+    {
+        if (!coherent)
+        {
+            __shared__ unsigned short lq[256];      /* (owner lane << 2) | light position in the chunk */
+            __shared__ u32 locc[64];                /* per owner: bit j = its j-th light of the chunk is occluded */
+            const int lane = (int)(threadIdx.x & 63u);
+            while (any_lane(le != 0))
+            {
+                /* ---- enumerate: which of its next four lights does each hit face (LT_cyc 2764-2790) ---- */
+                u32 lmbits = 0, cur = le;
+                int nl = 0, n_q = 0;
+                locc[lane] = 0u;
+#pragma nounroll
+                for (int j = 0; j < 4; j++)
+                {
+                    if (!any_lane(cur != 0)) break;
+                    const bool has = cur != 0;
+                    const CLight cl = *(const CLight *)(G + cur);
+                    const qr_light *__restrict__ lg = (const qr_light *)(G + (has ? (cl.lgt & ~QR_CLIGHT_LAST) : 0u));
+                    bool lm = false;
+                    if (has)
+                    {
+                        QR_FLOPS(8);
+                        float x1, x2, x3, x0;
+                        x1 = lg->pos[0] - hit.x; x1 = x1 * nrm.x;
+                        x2 = lg->pos[1] - hit.y; x2 = x2 * nrm.y;
+                        x3 = lg->pos[2] - hit.z; x3 = x3 * nrm.z;
+                        x0 = x1; x0 = x0 + x2; x0 = x0 + x3;
+                        lm = clt(0.0f, x0);
+                        nl++;
+                    }
+                    if (COUNT) { if (lm) cnt.shadow++; }
+                    if (QR_KNOB(2)) lm = false;
+                    const lm_t m = LM(lm);
+                    if (lm) { lq[n_q + lanes_below(m)] = (unsigned short)((lane << 2) | j); lmbits |= 1u << j; }
+                    n_q += __popcll(m);
+                    cur = (has && !(cl.lgt & QR_CLIGHT_LAST)) ? cur + (u32)sizeof(CLight) : 0u;
+                }
+                __syncthreads();
+                /* ---- trace: 64 (hit, light) pairs at a time ---- */
+                if (!QR_KNOB(1))
+                {
+#pragma nounroll
+                    for (int b0 = 0; b0 < n_q; b0 += 64)
+                    {
+                        const bool ta = b0 + lane < n_q;
+                        const u32 q = lq[ta ? b0 + lane : 0];
+                        const int own = ta ? (int)(q >> 2) : lane;
+                        const u32 jj = q & 3u;
+                        /* the owner's hit, from its registers (every lane executes the shuffles) */
+                        Ray sr;
+                        sr.org.x = __shfl(hit.x, own); sr.org.y = __shfl(hit.y, own); sr.org.z = __shfl(hit.z, own);
+                        sr.ploc.x = __shfl(h.loc.x, own); sr.ploc.y = __shfl(h.loc.y, own); sr.ploc.z = __shfl(h.loc.z, own);
+                        sr.osrf = (u32)__shfl((int)hsrf, own); sr.oflg = __shfl(side, own);
+                        const u32 ole = (u32)__shfl((int)le, own);
+                        const CLight cl = *(const CLight *)(G + (ta ? ole + jj * (u32)sizeof(CLight) : 0u));
+                        const qr_light *__restrict__ lg = (const qr_light *)(G + (ta ? (cl.lgt & ~QR_CLIGHT_LAST) : 0u));
+                        sr.dir.x = lg->pos[0] - sr.org.x; sr.dir.y = lg->pos[1] - sr.org.y; sr.dir.z = lg->pos[2] - sr.org.z;
+                        sr.tmin = 0.0f; sr.tmax = lg->t_max;
+                        u32 sl = ta ? cl.shadow : 0u;
+                        if (any_lane((sl & QR_LISTF_GRID) != 0))
+                        {
+                            if (sl & QR_LISTF_GRID)
+                            {
+                                const CGrid *__restrict__ gr = (const CGrid *)(G + (sl & ~31u));
+                                const u32 cp = gr->comps;
+                                const float la = (cp & 3u) == 0 ? sr.ploc.x : ((cp & 3u) == 1 ? sr.ploc.y : sr.ploc.z);
+                                const float lb = ((cp >> 2) & 3u) == 0 ? sr.ploc.x : (((cp >> 2) & 3u) == 1 ? sr.ploc.y : sr.ploc.z);
+                                int ia = cvt_floor((la - gr->org_a) * gr->inv_a), ib = cvt_floor((lb - gr->org_b) * gr->inv_b);
+                                const int nx = (int)gr->nx, ny = (int)gr->ny;
+                                ia = ia < 0 ? 0 : (ia >= nx ? nx - 1 : ia);
+                                ib = ib < 0 ? 0 : (ib >= ny ? ny - 1 : ib);
+                                sl = *(const u32 *)(G + (gr->table + (u32)(ib * nx + ia) * 4u));
+                            }
+                        }
+                        sr.list = sl;
+                        Hit sh; bool occ;
+#ifdef QR_WAVETIME
+                        const unsigned long long wt_s0 = __builtin_amdgcn_s_memrealtime();
+#endif
+                        traverse<true, DIVK>(B, ta, false, sr, sh, occ
+#ifdef QR_STATS
+                                             , cx.stats
+#endif
+                                             );
+#ifdef QR_WAVETIME
+                        if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_shadow += __builtin_amdgcn_s_memrealtime() - wt_s0;
+#endif
+                        if (ta && occ) atomicOr(&locc[own], 1u << jj);
+                    }
+                }
+                __syncthreads();
+                const u32 ob = locc[lane];
+                /* ---- the lights' terms, in list order ---- */
+#pragma nounroll
+                for (int j = 0; j < 4; j++)
+                {
+                    if (!any_lane(j < nl)) break;
+                    if (j < nl)
+                    {
+                        const CLight cl = *(const CLight *)(G + (le + (u32)j * (u32)sizeof(CLight)));
+                        const qr_light *__restrict__ lg = (const qr_light *)(G + (cl.lgt & ~QR_CLIGHT_LAST));
+                        if (((lmbits & ~ob) >> j) & 1u)
+                        {
+                            V3 L;
+                            float x1, x2, x3, x0;
+                            x1 = lg->pos[0] - hit.x; L.x = x1; x1 = x1 * nrm.x;
+                            x2 = lg->pos[1] - hit.y; L.y = x2; x2 = x2 * nrm.y;
+                            x3 = lg->pos[2] - hit.z; L.z = x3; x3 = x3 * nrm.z;
+                            x0 = x1; x0 = x0 + x2; x0 = x0 + x3;
+                            light_terms(G, mo, props, lg, L, x0, r, nrm, tex, col);
+                        }
+                    }
+                }
+                le = cur;
+                __syncthreads();                /* locc is cleared again at the top */
+            }
+        }
+    }
     /* lights, 2758-3156: wave-wide loop, per-lane light-list entries */
     while (any_lane(le != 0))
     {
@@ -337,107 +572,7 @@ __device__ __forceinline__ void shade(const Ctx &cx, bool act, bool coherent, co
             if (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) qr_wt_shadow += __builtin_amdgcn_s_memrealtime() - wt_s0;
 #endif
         }
-        if (lm && !occ)
-        {
-            const qr_material *__restrict__ mt = (const qr_material *)(G + mo);
-            float x0, x1, x2, x3, x4, x5, x6, x7;
-            x1 = L.x; x4 = x1 * x1;
-            x2 = L.y; x5 = x2 * x2;
-            x3 = L.z; x6 = x3 * x3;
-            x4 = x4 + x5; x4 = x4 + x6;
-            const float r2 = x4;
-            x0 = dot;
-            QR_FLOPS(10);
-            if (props & QR_PROP_DIFFUSE)
-            {
-                QR_FLOPS(17);
-                x6 = x4;
-                x5 = rsq(x4);
-                x4 = x5 * x6;
-                x6 = x6 * lg->a_qdr;
-                x4 = x4 * lg->a_lnr;
-                x6 = x6 + lg->a_cnt;
-                x6 = x6 + x4;
-                x4 = rsq(x6);
-                x6 = x0;
-                x0 = x0 * x4;
-                x0 = x0 * x5;
-                x0 = x0 * mt->l_dff;
-            }
-            else
-            {
-                x6 = x0;
-                x0 = 0.0f;
-            }
-            bool plain = false;
-            float spec = 0.0f;
-            if (props & QR_PROP_SPECULAR)
-            {
-                x4 = x6; x5 = x6;
-                x4 = x4 * nrm.x; x1 = x1 - x4; x1 = x1 - x4;
-                x5 = x5 * nrm.y; x2 = x2 - x5; x2 = x2 - x5;
-                x6 = x6 * nrm.z; x3 = x3 - x6; x3 = x3 - x6;
-                x4 = r.dir.x; x1 = x1 * x4; x4 = x4 * x4;
-                x5 = r.dir.y; x2 = x2 * x5; x5 = x5 * x5;
-                x6 = r.dir.z; x3 = x3 * x6; x6 = x6 * x6;
-                x6 = x6 + x4; x6 = x6 + x5;
-                x1 = x1 + x2; x1 = x1 + x3;
-                if (clt(0.0f, x1))
-                {
-                    QR_FLOPS(32);
-                    x4 = r2;
-                    x5 = rsq(x6); x1 = x1 * x5;
-                    x5 = rsq(x4); x1 = x1 * x5;
-                    /* fixed-point 28.4 power, 2981-3039 */
-                    const u32 lpow = mt->l_pow;
-                    u32 pw = lpow & 0xF;
-                    x2 = x1; x4 = x1; x1 = 1.0f;
-                    while (pw != 0)
-                    {
-                        x4 = __builtin_sqrtf(x4);
-                        const u32 bit = pw & 0x8;
-                        pw = (pw << 1) & 0xF;
-                        if (bit) x1 = x1 * x4;
-                    }
-                    pw = lpow >> 4;
-                    if (pw != 0)
-                    {
-                        x3 = x1; x1 = 1.0f;
-                        do
-                        {
-                            const u32 bit = pw & 1;
-                            pw >>= 1;
-                            if (bit) x1 = x1 * x2;
-                            x2 = x2 * x2;
-                        }
-                        while (pw != 0);
-                        x1 = x1 * x3;
-                    }
-                    x1 = x1 * mt->l_spc;
-                    if (props & QR_PROP_METAL) { x0 = x0 + x1; }
-                    else { plain = true; spec = x1; }
-                }
-            }
-            if (!plain)
-            {
-                x1 = tex.x * lg->col[0];
-                x2 = tex.y * lg->col[1];
-                x3 = tex.z * lg->col[2];
-                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
-                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
-            }
-            else
-            {
-                x7 = spec;
-                x1 = tex.x; x2 = tex.y; x3 = tex.z;
-                x4 = lg->col[0]; x5 = lg->col[1]; x6 = lg->col[2];
-                x1 = x1 * x0; x2 = x2 * x0; x3 = x3 * x0;
-                x1 = x1 * x4; x2 = x2 * x5; x3 = x3 * x6;
-                x4 = x4 * x7; x5 = x5 * x7; x6 = x6 * x7;
-                x1 = x1 + x4; x2 = x2 + x5; x3 = x3 + x6;
-                col.x = x1 + col.x; col.y = x2 + col.y; col.z = x3 + col.z;
-            }
-        }
+        if (lm && !occ) light_terms(G, mo, props, lg, L, dot, r, nrm, tex, col);
         le = (has && !(cl.lgt & QR_CLIGHT_LAST)) ? le + (u32)sizeof(CLight) : 0u;
     }
 

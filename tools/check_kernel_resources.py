@@ -15,7 +15,7 @@ LIMITS = {
     # mangled-name fragment: (max vgpr_count, max vgpr_spill_count, max private_segment_fixed_size)
     "16qr_render_kernelILb0ELi4ELb0EE": (128, 0, SCR),
     "22qr_render_multi_kernelILi4ELb0EE": (128, 0, SCR),
-    "16qr_render_kernelILb0ELi3ELb1EE": (168, int(os.environ.get("QR_MAX_DIVK_SPILL", "8")), 640),
+    "16qr_render_kernelILb0ELi3ELb1EE": (168, int(os.environ.get("QR_MAX_DIVK_SPILL", "24")), 640),
 }
 KEYS = ("name", "group_segment_fixed_size", "private_segment_fixed_size", "sgpr_count", "sgpr_spill_count", "vgpr_count", "vgpr_spill_count")
 
