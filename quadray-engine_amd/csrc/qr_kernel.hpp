@@ -63,6 +63,10 @@
 #define QR_KNOB(bit) false
 #endif
 #define QR_PER_LANE_TILE 0xFFFFFFFEu /* schedule entry: the footprint straddles tiles, look the list up per pixel (QR_SCHED_PER_LANE) */
+#ifndef QR_RETURN_LOOP
+#define QR_RETURN_LOOP 1     /* the instance with the per-lane walks: a lane unwinds all finished levels in one round (0: one level per round,
+                              * as the packet instance does: there it costs demo1 1 % of its isolated launch, A/B in profiles/r04_return_loop_ab.txt) */
+#endif
 #ifndef QR_DYN_PRIO
 #define QR_DYN_PRIO 1        /* issue priority follows the recursion round a wave is in (0: fixed by the footprint's class) */
 #endif
@@ -435,6 +439,7 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
     while (!eager_done && any_lane(mode != 2))
     {
         const bool tr = mode == 0;
+        bool ret_once = true;
 #ifdef QR_STATS
         {
             const unsigned long long n_tr = (unsigned long long)__popcll(__ballot(tr)), n_on = (unsigned long long)__popcll(__ballot(mode != 2));
@@ -571,8 +576,12 @@ __device__ __forceinline__ void render_wave(const LaunchP &lp, const u32 ord, co
             }
         }
 
-        if (mode == 1)
+        /* returns.  DIVK instance: a lane unwinds until its sample is finished or has its next ray (one level per round before
+         * round 4) -- a lane's state machine does not depend on its neighbours, and every unfinished lane then traces in every
+         * round: fewer, fuller rounds (config 5: +1.3 %).  The packet instance keeps one level per round */
+        while ((QR_RETURN_LOOP && DIVK) ? mode == 1 : (mode == 1 && ret_once))
         {
+            ret_once = false;
             if (sp == 0)
             {
                 mode = 2;
