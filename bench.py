@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--min-region-ms", type=float, default=250.0,
                     help="repeat the --steps pass back to back until the timed region lasts at least this long")
     ap.add_argument("--repetitions", type=int, default=0, help="passes of --steps inside the timed region (0: from --min-region-ms)")
+    ap.add_argument("--split-frame", action="store_true",
+                    help="N > 1: ONE frame per step, its 8-row tile rows dealt round-robin over the N ranks and gathered on rank 0 "
+                         "(strong scaling: north_star's 'tiles sharded across the GPUs, final image gathered'); default: N frames per step (weak)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: gather every frame on rank 0 (north_star's wording) instead of frame f on rank f")
     args = ap.parse_args()
@@ -286,15 +289,26 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(D)]
     compute = streams[0]
     comm = torch.cuda.Stream()
-    frames = [[scn.new_frame() for _ in range(N)] for _ in range(B)]    # render targets of the steps in flight
-    finals = [scn.new_frame() for _ in range(B)]                        # the frame this rank assembles
+    split = bool(args.split_frame and N > 1)
+    sp = sharding.SplitFrame(H, W, N, rank) if split else None
+
+    def split_frame_buffer():
+        # height rounded up to whole tile rows (the buffers are viewed as [tile row, 8, width]); the kernel writes rows < H
+        return torch.zeros((sp.alloc_rows, W), dtype=torch.int32, device=f"cuda:{local_rank}")
+    if split:
+        frames = [[split_frame_buffer()] for _ in range(B)]
+    else:
+        frames = [[scn.new_frame() for _ in range(N)] for _ in range(B)]    # render targets of the steps in flight
+    finals = [split_frame_buffer() if split else scn.new_frame() for _ in range(B)]     # the frame this rank assembles
     gfinals = [[scn.new_frame() for _ in range(N)] for _ in range(B)] if (args.gather and rank == 0 and N > 1) else None
     ev_render = [torch.cuda.Event() for _ in range(B)]
     ev_comm = [torch.cuda.Event() for _ in range(2)]                    # per group of D steps
     # the N blocks this rank owns in a step (block (rank + f) mod N of frame f) go out as ONE multi-target
     # launch (qr_render_multi_async): cut into N launches the same work costs 2-2.6x (ramp, drain and tail of
     # every small grid; measured on one GPU, tools/gpu_shard_overhead.py)
-    multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(B)] if N > 1 else None
+    multi = [qr.MultiRender([(scn, frames[b][f]) + ex.my_rows(f) for f in range(N)]) for b in range(B)] if (N > 1 and not split) else None
+    if split:
+        scn.set_tile_rows(rank, N)          # every launch of this rank from here on: tile rows rank, rank + N, ...
     state = {"pending": [], "timed": False, "ev": []}
 
     def flush():
@@ -308,7 +322,9 @@ def main():
                     # the exchange itself, on the stream it runs on: from the moment its inputs are rendered to its last copy
                     x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     x0.record(comm)
-                if args.gather:
+                if split:
+                    sp.gather([(frames[b][0], finals[b]) for b in state["pending"]], root=0)
+                elif args.gather:
                     ex.gather_many([(frames[b], gfinals[b] if gfinals else None) for b in state["pending"]], root=0)
                 else:
                     ex.exchange_many([(frames[b], finals[b]) for b in state["pending"]])
@@ -322,7 +338,10 @@ def main():
         buf = i % B
         st = streams[i % D]
         with torch.cuda.stream(st):
-            if N > 1:
+            if split:
+                st.wait_event(ev_comm[buf // D])
+                scn.render(frames[buf][0], stream=st)
+            elif N > 1:
                 st.wait_event(ev_comm[buf // D])            # the exchange that last read this group of buffers is done
                 multi[buf](stream=st)
             else:
@@ -421,7 +440,9 @@ def main():
     if N > 1:
         # the assembled frame must equal a whole-frame render of this rank (which passed the gate above)
         last = (total_steps - 1) % B
-        if args.gather:
+        if split:
+            ok = bool((gate == finals[last][:H]).all().item()) if rank == 0 else True
+        elif args.gather:
             ok = all(bool((gate == g).all().item()) for g in gfinals[last]) if rank == 0 else True
         else:
             ok = bool((gate == finals[last]).all().item())
@@ -442,7 +463,8 @@ def main():
         devs = [None] * N
         dist.all_gather_object(devs, f"rank {rank}: cuda:{torch.cuda.current_device()} {torch.cuda.get_device_name()}")
         collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": devs,
-                      "pattern": ("grouped point-to-point gather of row blocks to rank 0" if args.gather else
+                      "pattern": ("one frame's tile rows dealt round-robin, gathered on rank 0 by grouped point-to-point sends" if split else
+                                  "grouped point-to-point gather of row blocks to rank 0" if args.gather else
                                   "grouped point-to-point all-to-all of row blocks") + ", one call per step group (sharding.py)"}
         if state["ev"]:
             # per-step exchange time of THIS rank, HIP events on the communication stream inside the timed region (with the
@@ -454,11 +476,12 @@ def main():
 
     # dominant-kernel duration: HIP events recorded on the launch stream around full-frame launches
     scn.set_rows(0, H, 0, 1)
+    scn.set_tile_rows(0, 1)
     avg_ms, min_ms = scn.render_timed(frames[0][0], max(20, min(args.steps, 200)), stream=compute)
     torch.cuda.synchronize()
 
     if rank == 0:
-        frames_done = args.steps * N                    # per pass of --steps; dt is the median pass
+        frames_done = args.steps * (1 if split else N)  # per pass of --steps; dt is the median pass
         total_rays = rays_per_frame * frames_done
         value = total_rays / dt / 1e6
         cpu = None
@@ -553,13 +576,14 @@ def main():
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic scene (quadray-engine_amd/synth.py)" if snap.startswith("synth:") else
                      f"the reference's own scene: snapshot of the engine's scene graph (tests/golden/{snap}.qrs.gz), no dataset involved"),
             "config": {"workload": f"{args.workload}: {desc}", "resolution": [W, H],
-                       "frames_per_step": N, "steps_in_flight": D, "rays_per_frame": rays_per_frame,
+                       "frames_per_step": 1 if split else N, "steps_in_flight": D, "rays_per_frame": rays_per_frame,
                        "rays": rc.as_dict(),
-                       "parallelism": f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps" if N > 1 else "single GPU",
+                       "parallelism": (f"one frame per step, tile rows round-robin over {N} ranks, gathered on rank 0 per {D} steps" if split else
+                                       f"tile-row blocks x{N}, 1 multi-target launch/step, 1 grouped exchange per {D} steps") if N > 1 else "single GPU",
                        "fps": frames_done / dt, "msamples_per_s": samples_per_frame * frames_done / dt / 1e6,
                        "frame_check": frame_check, "assembled_frame_matches": ok},
             "timing": timing,

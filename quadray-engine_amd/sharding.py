@@ -133,3 +133,62 @@ class FrameExchange:
                 req.wait()
         for host, dev in recv_host:
             dev.copy_(host)
+
+
+class SplitFrame:
+    """ONE frame over `world` GPUs (BASELINE.json north_star: "shards framebuffer tiles across the 8 GPUs of one node with the
+    final image gathered"): strong scaling.  The 8-row tile rows of the frame are dealt round-robin -- tile row g belongs to
+    rank g mod world, the reference's own row interleave across threads (tracer.cpp:1144-1145) at tile-row granularity, so sky
+    and geometry spread evenly -- every rank renders its tile rows into a full-size frame buffer (qr_scene_set_tile_rows(rank,
+    world)), compacts them, and one grouped send per rank brings them to the root, which scatters them into the final frame.
+    Frame buffers are allocated with the height rounded up to whole tile rows (alloc_rows) so that they view as
+    [tile row, 8, width]."""
+
+    def __init__(self, height, width, world, rank):
+        self.h, self.w, self.world, self.rank = height, width, world, rank
+        self.groups = (height + TILE_H - 1) // TILE_H
+        self.alloc_rows = self.groups * TILE_H
+
+    def my_groups(self, rank=None):
+        return range(self.rank if rank is None else rank, self.groups, self.world)
+
+    def _view(self, frame):
+        return frame[: self.alloc_rows].view(self.groups, TILE_H, self.w)
+
+    def gather(self, steps, root=0, group=None):
+        """steps = [(frame, final)]: `frame` this rank's rendered buffer (alloc_rows x w), `final` the root's assembled frame
+        (alloc_rows x w; ignored elsewhere).  One grouped send/recv for all steps."""
+        world, rank = self.world, self.rank
+        if world == 1:
+            for frame, final in steps:
+                final.copy_(frame)
+            return
+        staged = steps[0][0].is_cuda and dist.get_backend(group) == "gloo"
+        if staged:
+            torch.cuda.current_stream().synchronize()
+        ops, keep, scatter = [], [], []
+        for frame, final in steps:
+            if rank == root:
+                fv = self._view(final)
+                fv[rank::world].copy_(self._view(frame)[rank::world])
+                for peer in range(world):
+                    if peer == root:
+                        continue
+                    n = len(self.my_groups(peer))
+                    if n == 0:
+                        continue
+                    buf = torch.empty((n, TILE_H, self.w), dtype=final.dtype, device="cpu" if staged else final.device)
+                    ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+                    scatter.append((buf, fv, peer))
+            else:
+                src = self._view(frame)[rank::world].contiguous()
+                if staged:
+                    src = src.cpu()
+                if src.numel():
+                    ops.append(dist.P2POp(dist.isend, src, root, group))
+                keep.append(src)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for buf, fv, peer in scatter:
+            fv[peer::world].copy_(buf)

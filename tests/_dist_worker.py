@@ -51,6 +51,22 @@ def main():
         for f in range(world):
             wf, _, _ = qr_oracle.render(blob, depth=f, threads=1)
             ok = ok and bool((gfin[f].numpy().view(np.uint32) == wf).all())
+    # ONE frame split over the ranks (bench.py --split-frame): tile row g rendered by rank g mod world, gathered on rank 0
+    sp = sharding.SplitFrame(h, w, world, rank)
+    mine = torch.zeros((sp.alloc_rows, w), dtype=torch.int32)
+    for g in sp.my_groups():
+        r0, r1 = g * 8, min(h, g * 8 + 8)
+        part, _, _ = qr_oracle.render(blob, depth=1, threads=1, rows=(r0, r1))
+        mine[r0:r1] = torch.from_numpy(part[r0:r1].astype(np.int64)).to(torch.int32)
+    sfin = [torch.zeros((sp.alloc_rows, w), dtype=torch.int32) for _ in range(2)]
+    sp.gather([(mine, sfin[0]), (mine ^ 5, sfin[1])], root=0)
+    if rank == 0:
+        w1, _, _ = qr_oracle.render(blob, depth=1, threads=1)
+        ok = ok and bool((sfin[0][:h].numpy().view(np.uint32) == w1).all()) and bool(((sfin[1][:h] ^ 5).numpy().view(np.uint32) == w1).all())
+    owned = torch.zeros(sp.groups, dtype=torch.int32)
+    owned[list(sp.my_groups())] += 1
+    dist.all_reduce(owned)
+    ok = ok and bool((owned == 1).all())
     # every row of every frame is rendered by exactly one rank
     cover = torch.zeros((world, h), dtype=torch.int32)
     for f in range(world):

@@ -151,7 +151,7 @@ def test_gpu_drop_in_path_tracer_through_reference_engine(args):
     assert hashes[0] == hashes[1], hashes
 
 
-@pytest.mark.parametrize("ranks,mode", [(2, []), (2, ["--gather"]), (4, []), (3, ["--gather"])])
+@pytest.mark.parametrize("ranks,mode", [(2, []), (2, ["--gather"]), (4, []), (3, ["--gather"]), (2, ["--split-frame"]), (3, ["--split-frame"])])
 def test_gpu_two_rank_bench_path_on_one_gpu(ranks, mode):
     """The N > 1 code path of bench.py -- MultiRender (one multi-target launch per step), the buffer rotation and
     the grouped exchange / gather -- with the HIP renderer, all ranks on this one GPU (gloo carries the exchange:
@@ -176,6 +176,28 @@ def test_gpu_two_rank_bench_path_on_one_gpu(ranks, mode):
     assert j["config"]["frame_check"]["timed_frames_match"] is True and j["config"]["assembled_frame_matches"] is True
     assert j["collective"]["ranks"] == ranks and j["collective"]["backend"] == "gloo"
     assert j["collective"]["exchange_groups"] >= 1 and j["collective"]["exchange_ms_per_step"] >= 0.0
+    assert j["scaling"] == ("strong" if "--split-frame" in mode else "weak")
+    assert j["config"]["frames_per_step"] == (1 if "--split-frame" in mode else ranks)
+
+
+def test_gpu_rccl_communicator_beside_the_hip_library():
+    """RCCL itself, as far as one GPU can take it: the `nccl` backend of torch.distributed with world size 1 in a process
+    that has libqrhip.so's HIP kernels loaded -- a communicator is created, a rendered frame goes through an all_gather, an
+    all_reduce and the sharding module's exchange / gather / split-frame paths on the backend bench.py uses with N > 1
+    (two HIP runtimes in one process would fail here: quadray-engine_amd/__init__.py loads torch's first).  What this does
+    NOT show is traffic between two devices: no such box exists in this pipeline."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_world1.py")], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "rccl ok" in out.stdout, out.stdout
 
 
 def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
@@ -205,7 +227,10 @@ def test_gpu_drop_in_bench_1080p_matches_and_reports_split(capsys):
         # the split of a frame of the timed loop (the last two calls of an animated run re-render one scene time)
         split = [l for l in out.stderr.splitlines() if l.startswith("qr_render0:")][-3 if "--animate" in extra else -1]
         report += [" ".join(extra) or "(frozen)", cpu, line, split]
-        assert float(re.search(r"median_ms ([0-9.]+)", line).group(1)) < 5.0
+        # rt_Scene::render through the HIP backend, median of 50 frames: 0.66-0.80 ms frozen, 1.18-1.26 ms animated on the rounds'
+        # boxes (DESIGN.md 5 "Drop-in"); the bounds catch a regression of 1.5x without tripping on a slower host
+        med = float(re.search(r"median_ms ([0-9.]+)", line).group(1))
+        assert med < (2.0 if "--animate" in extra else 1.2), (extra, line, split)
     with capsys.disabled():
         print("\n" + "\n".join(report))
 

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+for rep in 1 2; do
+for L in libqrhip.so libqrhip_db8.so libqrhip_db24.so libqrhip_dd8.so libqrhip_dd2.so libqrhip_mo48.so libqrhip_mo20.so; do
+  QR_LIB=$R/quadray-engine_amd/$L python bench.py --workload synth10k_4320p --steps 30 --warmup 5 --no-cpu-baseline --repetitions 1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['value'],1), 'Mrays/s', 'isolated', round(d['roofline']['kernel_avg_ms'],4))" | tee -a $O/r4h_knobs.txt
+done; done
