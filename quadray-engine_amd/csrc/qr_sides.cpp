@@ -318,38 +318,68 @@ int QrSideGeom::clip_side(int srf, const float *pos) const
     return surf_cbox(s, pos) != 0 ? 3 : c;
 }
 
-/* vert_face 314-441: does the segment p0-p1 meet the quad q0-q1-q2 (two edges from q0); 2 = strictly between */
+/*
+ * Geometry helpers of the two crossing tests below.  The predicates must agree with the engine's fp32 results bit for bit
+ * (tests/test_lists.py: every list of 43 scenes member for member), which fixes the ORDER of the arithmetic -- differences,
+ * cross products with rtgeom.h:135-141's operand order, left-to-right sums, a tolerance of kThr on parameters and of th * kThr
+ * on windows -- but not how the code is cut: here a crossing test is "a parameter num / den with den >= 0" plus "windows the
+ * other coordinates must fall into", and both tests share the classification of that parameter.
+ */
+struct F3 { float x, y, z; };
+static inline F3 f3(const float *p) { F3 r = { p[0], p[1], p[2] }; return r; }
+static inline F3 f3_sub(const float *a, const float *b) { F3 r = { a[0] - b[0], a[1] - b[1], a[2] - b[2] }; return r; }
+static inline F3 f3_cross(const F3 &a, const F3 &b) { F3 r = { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; return r; }
+static inline float f3_dot(const F3 &a, const F3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float flip_if(float v, bool neg) { return neg ? -v : v; }
+
+/* is v outside [lo, hi] once both ends are scaled by den (den >= 0)? */
+static inline bool off_window(float v, float lo, float hi, float den) { return v < lo * den || v > hi * den; }
+
+/* where num / den (den >= 0) lies on the unit interval: 1 beyond its end, 3 at the end, 2 strictly inside, 4 at the start,
+ * 0 before it -- the codes of the engine's vert_face / edge_edge (rtgeom.cpp:436-440, 587-591) */
+static inline int unit_zone(float num, float den)
+{
+    if (num > (1.0f + kThr) * den) return 1;
+    if (num >= (1.0f - kThr) * den) return 3;
+    if (num > (0.0f + kThr) * den) return 2;
+    if (num >= (0.0f - kThr) * den) return 4;
+    return 0;
+}
+
+/* the segment a-b against an axis-aligned rectangle: normal axis k, spanned along i by c0-c1 and along j by c0-c2 */
+static int seg_rect_aligned(const float *a, const float *b, int th, const float *c0, const float *c1, const float *c2, int k, int i, int j)
+{
+    const float slack = (float)th * kThr;
+    float den = b[k] - a[k];
+    const float num = flip_if(c0[k] - a[k], den < 0.0f);
+    den = fabsf(den);
+    const float at_i = (b[i] - a[i]) * num;
+    if (off_window(at_i, fminf(c0[i], c1[i]) - a[i] - slack, fmaxf(c0[i], c1[i]) - a[i] + slack, den)) return 0;
+    const float at_j = (b[j] - a[j]) * num;
+    if (off_window(at_j, fminf(c0[j], c2[j]) - a[j] - slack, fmaxf(c0[j], c2[j]) - a[j] + slack, den)) return 0;
+    return unit_zone(num, den);
+}
+
+/* ... and against a parallelogram in general position (corner c0, edges to c1 and c2): barycentric windows [0, 1] */
+static int seg_quad(const float *a, const float *b, int th, const float *c0, const float *c1, const float *c2)
+{
+    const float slack = (float)th * kThr;
+    const F3 e1 = f3_sub(c1, c0), e2 = f3_sub(c2, c0), dir = f3_sub(b, a), rel = f3_sub(a, c0);
+    const F3 m = f3_cross(dir, e2);
+    float den = f3_dot(e1, m);
+    const bool neg = den < 0.0f;
+    den = fabsf(den);
+    if (off_window(flip_if(f3_dot(rel, m), neg), 0.0f - slack, 1.0f + slack, den)) return 0;
+    const F3 n = f3_cross(rel, e1);
+    if (off_window(flip_if(f3_dot(dir, n), neg), 0.0f - slack, 1.0f + slack, den)) return 0;
+    return unit_zone(flip_if(f3_dot(e2, n), neg), den);
+}
+
+/* vert_face (rtgeom.cpp:314-441): where along the segment p0-p1 it passes through the face q0-q1-q2; qk / qi / qj < 3 name the
+ * axes of an axis-aligned face */
 static int vert_face(const float *p0, const float *p1, int th, const float *q0, const float *q1, const float *q2, int qk, int qi, int qj)
 {
-    float d, s, t, u, w;
-    if (qk < 3 && qi < 3 && qj < 3)
-    {
-        d = p1[qk] - p0[qk];
-        t = q0[qk] - p0[qk];
-        t = d < 0.0f ? -t : +t;
-        d = fabsf(d);
-        u = (p1[qi] - p0[qi]) * t;
-        if (u < (fminf(q0[qi], q1[qi]) - p0[qi] - (float)th * kThr) * d || u > (fmaxf(q0[qi], q1[qi]) - p0[qi] + (float)th * kThr) * d) return 0;
-        w = (p1[qj] - p0[qj]) * t;
-        if (w < (fminf(q0[qj], q2[qj]) - p0[qj] - (float)th * kThr) * d || w > (fmaxf(q0[qj], q2[qj]) - p0[qj] + (float)th * kThr) * d) return 0;
-    }
-    else
-    {
-        float e1[3], e2[3], pr[3], qr[3], mx[3], nx[3];
-        for (int a = 0; a < 3; a++) { e1[a] = q1[a] - q0[a]; e2[a] = q2[a] - q0[a]; pr[a] = p1[a] - p0[a]; qr[a] = p0[a] - q0[a]; }
-        /* RT_VEC3_MUL, rtgeom.h:135-141 */
-        mx[0] = pr[1] * e2[2] - e2[1] * pr[2]; mx[1] = pr[2] * e2[0] - e2[2] * pr[0]; mx[2] = pr[0] * e2[1] - e2[0] * pr[1];
-        d = dot3(e1, mx);
-        s = d < 0.0f ? -1.0f : +1.0f;
-        d = fabsf(d);
-        u = dot3(qr, mx) * s;
-        if (u < (0.0f - (float)th * kThr) * d || u > (1.0f + (float)th * kThr) * d) return 0;
-        nx[0] = qr[1] * e1[2] - e1[1] * qr[2]; nx[1] = qr[2] * e1[0] - e1[2] * qr[0]; nx[2] = qr[0] * e1[1] - e1[0] * qr[1];
-        w = dot3(pr, nx) * s;
-        if (w < (0.0f - (float)th * kThr) * d || w > (1.0f + (float)th * kThr) * d) return 0;
-        t = dot3(e2, nx) * s;
-    }
-    return t > (1.0f + kThr) * d ? 1 : t >= (1.0f - kThr) * d ? 3 : t > (0.0f + kThr) * d ? 2 : t >= (0.0f - kThr) * d ? 4 : 0;
+    return (qk < 3 && qi < 3 && qj < 3) ? seg_rect_aligned(p0, p1, th, q0, q1, q2, qk, qi, qj) : seg_quad(p0, p1, th, q0, q1, q2);
 }
 
 /* bbox_fuse 1853-1943: 0 apart, 1 possibly one inside the other, 2 borders intersect (or no bounds to tell) */
@@ -422,94 +452,109 @@ int QrSideGeom::side(int ref, int srf) const
     return c;
 }
 
-/* edge_edge 449-592: do the edges p1-p2 and q1-q2 cross as seen from p0; 1 = the first edge lies between p0 and the second */
+/* two axis-aligned edges seen from `eye`: the first runs along axis pa from a1 to a2, the second along qa from b1 to b2; the
+ * third axis carries the depth order */
+static int edges_aligned(const float *eye, int th, const float *a1, const float *a2, int pa, const float *b1, const float *b2, int qa)
+{
+    if (pa == qa) return 0;                                 /* parallel edges never cross */
+    const float slack = (float)th * kThr;
+    const int depth_axis = 3 - pa - qa;
+    float near_d = a1[depth_axis] - eye[depth_axis];
+    float far_d = b1[depth_axis] - eye[depth_axis];
+    near_d = flip_if(near_d, far_d < 0.0f);
+    far_d = fabsf(far_d);
+    const float at_p = (b1[pa] - eye[pa]) * near_d;
+    if (off_window(at_p, fminf(a1[pa], a2[pa]) - eye[pa] - slack, fmaxf(a1[pa], a2[pa]) - eye[pa] + slack, far_d)) return 0;
+    far_d = flip_if(far_d, near_d < 0.0f);
+    near_d = fabsf(near_d);
+    const float at_q = (a1[qa] - eye[qa]) * far_d;
+    if (off_window(at_q, fminf(b1[qa], b2[qa]) - eye[qa] - slack, fmaxf(b1[qa], b2[qa]) - eye[qa] + slack, near_d)) return 0;
+    return unit_zone(far_d, near_d);
+}
+
+/* ... and two edges in general position */
+static int edges_general(const float *eye, int th, const float *a1, const float *a2, const float *b1, const float *b2)
+{
+    const float slack = (float)th * kThr;
+    const F3 ea = f3_sub(a2, a1), eb = f3_sub(b2, b1), ra = f3_sub(a1, eye), rb = f3_sub(b1, eye);
+    const F3 m = f3_cross(eb, ea), n = f3_cross(rb, ra);
+    float far_d = f3_dot(rb, m);
+    bool neg = far_d < 0.0f;
+    far_d = fabsf(far_d);
+    if (off_window(flip_if(f3_dot(eb, n), neg), 0.0f - slack, 1.0f + slack, far_d)) return 0;
+    far_d = flip_if(far_d, neg);
+    float near_d = f3_dot(ra, m);
+    neg = near_d < 0.0f;
+    near_d = fabsf(near_d);
+    if (off_window(flip_if(f3_dot(ea, n), neg), 0.0f - slack, 1.0f + slack, near_d)) return 0;
+    far_d = flip_if(far_d, neg);
+    return unit_zone(far_d, near_d);
+}
+
+/* edge_edge (rtgeom.cpp:449-592): do the edges p1-p2 and q1-q2 cross as seen from p0, and in which order (1: the first edge lies
+ * between p0 and the second); pk / qk < 3 name the axis of an axis-aligned edge */
 static int edge_edge(const float *p0, int th, const float *p1, const float *p2, int pk, const float *q1, const float *q2, int qk)
 {
-    float d, s, t, u, w;
-    if (pk < 3 && qk < 3)
-    {
-        if (pk == qk) return 0;
-        static const int mp[3][3] = { {0, 2, 1}, {2, 1, 0}, {1, 0, 2} };
-        const int kk = mp[pk][qk];
-        d = p1[kk] - p0[kk];
-        t = q1[kk] - p0[kk];
-        d = t < 0.0f ? -d : +d;
-        t = fabsf(t);
-        u = (q1[pk] - p0[pk]) * d;
-        if (u < (fminf(p1[pk], p2[pk]) - p0[pk] - (float)th * kThr) * t || u > (fmaxf(p1[pk], p2[pk]) - p0[pk] + (float)th * kThr) * t) return 0;
-        t = d < 0.0f ? -t : +t;
-        d = fabsf(d);
-        w = (p1[qk] - p0[qk]) * t;
-        if (w < (fminf(q1[qk], q2[qk]) - p0[qk] - (float)th * kThr) * d || w > (fmaxf(q1[qk], q2[qk]) - p0[qk] + (float)th * kThr) * d) return 0;
-    }
-    else
-    {
-        float ep[3], eq[3], pr[3], qr[3], mx[3], nx[3];
-        for (int a = 0; a < 3; a++) { ep[a] = p2[a] - p1[a]; eq[a] = q2[a] - q1[a]; pr[a] = p1[a] - p0[a]; qr[a] = q1[a] - p0[a]; }
-        mx[0] = eq[1] * ep[2] - ep[1] * eq[2]; mx[1] = eq[2] * ep[0] - ep[2] * eq[0]; mx[2] = eq[0] * ep[1] - ep[0] * eq[1];
-        nx[0] = qr[1] * pr[2] - pr[1] * qr[2]; nx[1] = qr[2] * pr[0] - pr[2] * qr[0]; nx[2] = qr[0] * pr[1] - pr[0] * qr[1];
-        t = dot3(qr, mx);
-        s = t < 0.0f ? -1.0f : +1.0f;
-        t = fabsf(t);
-        u = dot3(eq, nx) * s;
-        if (u < (0.0f - (float)th * kThr) * t || u > (1.0f + (float)th * kThr) * t) return 0;
-        t *= s;
-        d = dot3(pr, mx);
-        s = d < 0.0f ? -1.0f : +1.0f;
-        d = fabsf(d);
-        w = dot3(ep, nx) * s;
-        if (w < (0.0f - (float)th * kThr) * d || w > (1.0f + (float)th * kThr) * d) return 0;
-        t *= s;
-    }
-    return t > (1.0f + kThr) * d ? 1 : t >= (1.0f - kThr) * d ? 3 : t > (0.0f + kThr) * d ? 2 : t >= (0.0f - kThr) * d ? 4 : 0;
+    return (pk < 3 && qk < 3) ? edges_aligned(p0, th, p1, p2, pk, q1, q2, qk) : edges_general(p0, th, p1, p2, q1, q2);
 }
 
 static inline float asin32(float a) { return a <= -1.0f ? -(float)(3.14159265358979323846 / 2.0) : a >= 1.0f ? (float)(3.14159265358979323846 / 2.0) : asinf(a); }
 static inline float acos32(float a) { return a <= -1.0f ? (float)3.14159265358979323846 : a >= 1.0f ? 0.0f : acosf(a); }
 static inline float len3(const float *a) { const float d = dot3(a, a); return d <= 0.0f ? 0.0f : sqrtf(d); }
 
-/* bbox_shad 1004-1153: may the box `i1` cast a shadow on the box `i2` as seen from the point `pps` (a light) */
+/* half-angle of the cone from `eye` around a sphere of radius r at distance l (the whole space when the eye is inside) */
+static inline float cone_half_angle(float l, float r)
+{
+    return (l >= r && l > kThr) ? asin32(r / l) : (float)(2.0 * 3.14159265358979323846);
+}
+
+/* bbox_shad (rtgeom.cpp:1004-1153): may the box `i1` cast a shadow on the box `i2` as seen from the point `pps` (a light).
+ * Three stages, each able to say "no": the cones around the two bounding spheres do not overlap; the caster's sphere lies
+ * clear behind the receiver's; no corner, face or edge of one box lines up with the other. */
 int QrSideGeom::shad(const float *pps, int i1, int i2) const
 {
-    const Box &n1 = box[i1], &n2 = box[i2];
-    if (n1.rad == kInf || n2.rad == kInf || i1 == i2) return 1;
+    const Box &caster = box[i1], &recv = box[i2];
+    if (caster.rad == kInf || recv.rad == kInf || i1 == i2) return 1;
     /* clip relations between two surfaces, RT_OPTS_SHADOW_EXT2 */
-    if (!n1.array && !n2.array && (surf_clip(i2, i1) != 0 || surf_clip(i1, i2) != 0)) return 1;
+    if (!caster.array && !recv.array && (surf_clip(i2, i1) != 0 || surf_clip(i1, i2) != 0)) return 1;
 
-    /* cones around the bounding spheres */
-    float v1[3], v2[3];
-    for (int a = 0; a < 3; a++) { v1[a] = n1.mid[a] - pps[a]; v2[a] = n2.mid[a] - pps[a]; }
-    const float l1 = len3(v1), l2 = len3(v2);
-    float ang = dot3(v1, v2);
-    ang = l1 <= kThr ? 0.0f : ang / l1;
-    const float a1 = l1 >= n1.rad && l1 > kThr ? asin32(n1.rad / l1) : (float)(2.0 * 3.14159265358979323846);
-    ang = l2 <= kThr ? 0.0f : ang / l2;
-    const float a2 = l2 >= n2.rad && l2 > kThr ? asin32(n2.rad / l2) : (float)(2.0 * 3.14159265358979323846);
-    ang = acos32(ang);
-    if (a1 + a2 < ang) return 0;
+    /* stage 1: view cones */
+    const float to_c[3] = { caster.mid[0] - pps[0], caster.mid[1] - pps[1], caster.mid[2] - pps[2] };
+    const float to_r[3] = { recv.mid[0] - pps[0], recv.mid[1] - pps[1], recv.mid[2] - pps[2] };
+    const float dist_c = len3(to_c), dist_r = len3(to_r);
+    float cosine = dot3(to_c, to_r);
+    cosine = dist_c <= kThr ? 0.0f : cosine / dist_c;
+    const float half_c = cone_half_angle(dist_c, caster.rad);
+    cosine = dist_r <= kThr ? 0.0f : cosine / dist_r;
+    const float half_r = cone_half_angle(dist_r, recv.rad);
+    if (half_c + half_r < acos32(cosine)) return 0;
 
-    /* the caster's sphere entirely behind the receiver's */
-    const float dv[3] = { n1.mid[0] - n2.mid[0], n1.mid[1] - n2.mid[1], n1.mid[2] - n2.mid[2] };
-    if (n1.rad + n2.rad < len3(dv) && l1 > l2) return 0;
+    /* stage 2: spheres apart and the caster the farther one */
+    const float apart[3] = { caster.mid[0] - recv.mid[0], caster.mid[1] - recv.mid[1], caster.mid[2] - recv.mid[2] };
+    if (caster.rad + recv.rad < len3(apart) && dist_c > dist_r) return 0;
 
-    /* box geometry, RT_OPTS_SHADOW_EXT1 */
-    if (n1.nverts == 0 || n2.nverts == 0) return 1;
-    if (node_bbox(n1, pps) != 0) return 1;
-    for (int q = 0; q < n1.nverts; q++)
-        for (int f = 0; f < n2.nfaces; f++)
-            if (vert_face(pps, n1.verts[q], +1, n2.verts[kFaces[f][0]], n2.verts[kFaces[f][1]], n2.verts[kFaces[f][3]],
-                          n2.face_k[f], n2.face_i[f], n2.face_j[f]) == 1) return 1;
-    for (int q = 0; q < n2.nverts; q++)
-        for (int f = 0; f < n1.nfaces; f++)
+    /* stage 3: box geometry, RT_OPTS_SHADOW_EXT1 */
+    if (caster.nverts == 0 || recv.nverts == 0) return 1;
+    if (node_bbox(caster, pps) != 0) return 1;
+    /* a sight line to a corner of one box through a face of the other: the caster's corner in front of the receiver's face
+     * (zone 1: the face lies beyond the corner), or the receiver's corner behind the caster's face (zones 2 / 4) */
+    auto face_zone = [&](const float *corner, const Box &b, int f) {
+        return vert_face(pps, corner, +1, b.verts[kFaces[f][0]], b.verts[kFaces[f][1]], b.verts[kFaces[f][3]], b.face_k[f], b.face_i[f], b.face_j[f]);
+    };
+    for (int q = 0; q < caster.nverts; q++)
+        for (int f = 0; f < recv.nfaces; f++)
+            if (face_zone(caster.verts[q], recv, f) == 1) return 1;
+    for (int q = 0; q < recv.nverts; q++)
+        for (int f = 0; f < caster.nfaces; f++)
         {
-            const int k = vert_face(pps, n2.verts[q], +1, n1.verts[kFaces[f][0]], n1.verts[kFaces[f][1]], n1.verts[kFaces[f][3]],
-                                    n1.face_k[f], n1.face_i[f], n1.face_j[f]);
-            if (k == 2 || k == 4) return 1;
+            const int z = face_zone(recv.verts[q], caster, f);
+            if (z == 2 || z == 4) return 1;
         }
-    for (int e = 0; e < n1.nedges; e++)
-        for (int g = 0; g < n2.nedges; g++)
-            if (edge_edge(pps, +1, n1.verts[kEdges[e][0]], n1.verts[kEdges[e][1]], n1.edge_k[e],
-                          n2.verts[kEdges[g][0]], n2.verts[kEdges[g][1]], n2.edge_k[g]) == 1) return 1;
+    /* silhouettes crossing with the caster's edge in front */
+    for (int e = 0; e < caster.nedges; e++)
+        for (int g = 0; g < recv.nedges; g++)
+            if (edge_edge(pps, +1, caster.verts[kEdges[e][0]], caster.verts[kEdges[e][1]], caster.edge_k[e],
+                          recv.verts[kEdges[g][0]], recv.verts[kEdges[g][1]], recv.edge_k[g]) == 1) return 1;
     return 0;
 }
 
