@@ -98,6 +98,21 @@ for w, e in cj.items():
     lines.append(w + ": " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in e.items() if k not in ("source", "git", "lib")) + "\n")
 open(os.path.join(P, f"{rnd}_counters_all_workloads.txt"), "w").write("".join(lines))
 
+# kernel-side work counts of this build (tools/gpu_work.py on the GPU box writes gpurun_out/work_kernel.json): into work.json
+wk = os.path.join(G, "work_kernel.json")
+if os.path.exists(wk):
+    wj = os.path.join(ROOT, "tests", "golden", "work.json")
+    work = json.load(open(wj)); new = json.load(open(wk))
+    for snap, e in new.items():
+        work.setdefault(snap, {})["kernel"] = {x: e[x] for x in ("flops", "rays", "primary", "shadow", "reflect", "refract", "cull_flops", "source")}
+    json.dump(work, open(wj, "w"), indent=1, sort_keys=True)
+    shutil_copy = os.path.join(P, f"{rnd}_work_kernel_side.json")
+    json.dump(new, open(shutil_copy, "w"), indent=1, sort_keys=True)
+for extra in ("timeline_events_demo1_1080p.txt", "timeline_waves_demo1_1080p.txt", "bench_steps20_a.json", "bench_steps20_b.json"):
+    src = os.path.join(G, f"{tag}_{extra}")
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        open(os.path.join(P, f"{rnd}_{extra}"), "w").write(open(src).read())
+
 import shutil
 for f in glob.glob(os.path.join(G, f"{tag}_bench_*.json")):
     name = os.path.basename(f)[len(tag) + 1:]
