@@ -71,7 +71,10 @@ o2 += [l + "\n" for l in kernel_stats(f"{tag}_trace_inflight3")]
 o2.append("\n# dispatch intervals of qr_render_kernel<false,4> from the trace (Start/End timestamps):\n")
 o2.append(json.dumps(ov, indent=1) + "\n")
 o2.append("# mean_dispatch_us = duration of one launch while others run beside it; span_per_dispatch_us = wall time per frame;\n"
-          "# time_with_n_in_flight = share of the busy time with n render dispatches executing at once\n")
+          "# time_with_n_in_flight = share of the busy time with n render dispatches executing at once\n"
+          "# NOTE: this is the launch pipeline UNDER THE PROFILER (rocprofv3 serialises dispatches from different streams: ~280 us per\n"
+          f"# dispatch).  The same mode without the profiler is profiles/{rnd}_timeline_events_demo1_1080p.txt (HIP events around every launch)\n"
+          f"# and profiles/{rnd}_timeline_waves_demo1_1080p.txt (s_memrealtime stamps of every wave): ~44 us per frame, three launches resident.\n")
 open(os.path.join(P, f"{rnd}_kernel_trace_inflight3.txt"), "w").write("".join(o2))
 
 cj = {}
