@@ -192,6 +192,28 @@ def test_gpu_synth_10k_objects_match_oracle(qr, oracle, seed):
 
 
 @pytest.mark.gpu
+def test_gpu_synth_10k_full_size_bands_match_oracle(qr, oracle):
+    """BASELINE config 5 at its FULL size (7680x4320, depth 4, 10 000 objects, lists and tile lists as bench.py builds them):
+    the oracle cannot walk the whole frame in test time, so three bands of rows -- top of the object cloud, the middle, the
+    ground plane near the bottom: 144 rows, 1.1 M pixels -- are compared pixel for pixel, and the frame's ray counts must be
+    those of the counting kernel variant twice in a row (determinism at 33 M pixels).  Until round 4 this check only ran inside
+    `bench.py --workload synth10k_4320p`."""
+    import torch
+    blob = qr.build_lists(_synth().make_scene(shadow_lists=False, width=7680, height=4320, depth=4))
+    scn = qr.Scene(blob, rebin_tiles=True)
+    assert (scn.width, scn.height) == (7680, 4320)
+    frame = scn.render(); torch.cuda.synchronize()
+    out = frame.cpu().numpy().view(np.uint32)
+    for r0 in (1200, 2136, 3600):
+        band, _, _ = oracle.render(blob, threads=16, rows=(r0, r0 + 48))
+        assert int((out[r0:r0 + 48] != band[r0:r0 + 48]).sum()) == 0, f"rows {r0}..{r0 + 48} differ from the oracle"
+    _, c1 = scn.render_count(); _, c2 = scn.render_count()
+    assert c1.as_dict() == c2.as_dict() and c1.primary == 7680 * 4320
+    again = scn.render(); torch.cuda.synchronize()
+    assert bool((again == frame).all())
+
+
+@pytest.mark.gpu
 def test_gpu_synth_multi_target_launch_matches_whole_frame(qr):
     """The multi-target launch of the kernel instance with the per-lane walks (qr_render_multi_kernel<.., true>): three
     row blocks of the 2000-object scene (walk_pool, shadow grids) and a block of an engine scene in ONE launch equal
