@@ -22,8 +22,12 @@
  * of transform nodes ("trnodes": nodes with a non-trivial rotation) and every node's axis mapping and scalers stay
  * the same, and no array with a bounding volume moves -- unless the node tables carry the bounds inputs and
  * QR_HIER_BOUNDS is given: then clip boxes and bounding volumes are recomputed like the engine does (rt_Surface::
- * update_minmax, rt_Array::update_bounds) and only a changing SET of transform nodes (list structure: snode / ssort) is
- * refused with QR_ERR_UNSUP.
+ * update_minmax, rt_Array::update_bounds).  A changing SET of transform nodes (round 4): an ARRAY may start or stop being
+ * the transform node of surfaces that hang directly in the global list and take no part in custom clipping -- the rotating
+ * light arrays of the demo scenes; qr_hierarchy_apply then creates (drops) the node's record and its element of the global
+ * list, needs both node tables (`base`) and QR_HIER_RESET_TILES, and returns a LARGER snapshot.  Members inside another
+ * array's run of the list, or clippers, would need the engine's ordered insert (engine.cpp:1116-1645, rtgeom.cpp:1244) and
+ * are refused with QR_ERR_UNSUP naming the node.
  *
  * Plain C ABI; fp32 arithmetic in the reference's operation order: the results are bit-identical to the engine's
  * (tests/test_hierarchy.py, fixtures dumped from the engine by oracle/ref_driver.cpp --tree).

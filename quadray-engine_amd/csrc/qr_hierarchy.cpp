@@ -12,6 +12,8 @@
 #include <cfloat>
 #include <cmath>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include <cstdlib>
 #include <cstring>
 
@@ -307,6 +309,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     int rc = qr_snapshot_validate(v, err);
     if (rc != QR_OK) return qr_fail(rc, err);
     std::vector<qr_node_state> st((size_t)(n > 0 ? n : 0)), st0;
+    std::vector<std::pair<int, int>> born_of, died_of;      /* (array node, member surface node): transform nodes that appear / vanish */
     rc = run_update(next, n, opts, st.data(), err);
     if (rc != QR_OK) return qr_fail(rc, err);
     const int n_srf = (int)v.hdr->n_srf, n_lgt = (int)v.hdr->n_lgt;
@@ -317,7 +320,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         for (int r : refs) if (r < -1 || r >= n_srf) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": surface record out of range");
         if (nd.tag == QR_NODE_LIGHT && (nd.lgt < -1 || nd.lgt >= n_lgt)) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": light record out of range");
         if (st[(size_t)i].trnode >= 0 && st[(size_t)i].trnode != i && (is_surface(nd.tag) || nd.tag == QR_NODE_ARRAY) && nd.srf >= 0
-            && next[st[(size_t)i].trnode].srf < 0)
+            && next[st[(size_t)i].trnode].srf < 0 && (base == nullptr || !is_surface(nd.tag)))
             return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": its transform node has no record in the snapshot");
     }
     if (camera >= n || (camera >= 0 && next[camera].tag != QR_NODE_CAMERA)) return qr_fail(QR_ERR_ARG, "camera is not a camera node");
@@ -337,7 +340,22 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                 return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": the two node tables describe different trees");
             const bool has_record = (is_surface(next[i].tag) || next[i].tag == QR_NODE_ARRAY) && next[i].srf >= 0;
             if (has_record && (a.trnode != b.trnode || a.obj_has_trm != b.obj_has_trm))
+            {
+                /* The set of transform nodes changes.  Supported (round 4): an ARRAY starts or stops being the transform node
+                 * of surfaces that hang directly in the global list -- the rotating light arrays of the demo scenes, whose
+                 * bulb becomes the member of a transform node the moment the array leaves a right angle (scn_demo01.h:513-561).
+                 * The record and the list element of such a node are created / removed below; everything else still needs the
+                 * engine's snode / insert (engine.cpp:1116-1814) and is refused. */
+                const int t_new = b.trnode, t_old = a.trnode;
+                const bool born = is_surface(next[i].tag) && t_old < 0 && t_new >= 0 && t_new != i && next[t_new].tag == QR_NODE_ARRAY
+                               && st0[(size_t)t_new].trnode < 0;
+                const bool died = is_surface(next[i].tag) && t_new < 0 && t_old >= 0 && t_old != i && next[t_old].tag == QR_NODE_ARRAY
+                               && next[t_old].srf >= 0 && st[(size_t)t_old].trnode < 0;
+                if (born) { born_of.push_back(std::make_pair(t_new, i)); continue; }
+                if (died) { died_of.push_back(std::make_pair(t_old, i)); continue; }
+                if (next[i].tag == QR_NODE_ARRAY && next[i].srf >= 0 && b.trnode != i && a.trnode == i) continue;   /* the array that stops: handled through its members */
                 return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
+            }
             if (has_record && !(flags & QR_HIER_BOUNDS) &&
                 (!same_bits(a.map, b.map, sizeof(a.map)) || !same_bits(a.sgn, b.sgn, sizeof(a.sgn)) || !same_bits(a.scl, b.scl, sizeof(a.scl))))
                 return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": axis mapping or scalers change (clip boxes would; QR_HIER_BOUNDS recomputes them)");
@@ -351,10 +369,149 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         }
     }
 
-    std::vector<uint8_t> out((const uint8_t *)blob, (const uint8_t *)blob + v.hdr->total_bytes);
-    qr_surface *S = (qr_surface *)(out.data() + v.hdr->off_srf);
-    qr_light *L = (qr_light *)(out.data() + v.hdr->off_lgt);
-    qr_frame *F = (qr_frame *)(out.data() + v.hdr->off_frame);
+    /* ---- transform nodes that appear or vanish: records, and the elements of the global list ---- */
+    std::vector<qr_node> nodes_w;                           /* `next` with the records of new transform nodes entered */
+    std::vector<qr_surface> S_w;
+    std::vector<qr_elem> E_w;
+    int32_t clist_w = v.frame->clist;
+    const bool restructure = !born_of.empty() || !died_of.empty();
+    if (restructure)
+    {
+        if (!(flags & QR_HIER_RESET_TILES))
+            return qr_fail(QR_ERR_ARG, "the set of transform nodes changes: the tile lists go stale, pass QR_HIER_RESET_TILES (and rebuild the lists)");
+        nodes_w.assign(next, next + n);
+        S_w.assign(v.srf, v.srf + v.hdr->n_srf);
+        E_w.assign(v.elm, v.elm + v.hdr->n_elm);
+        /* a member must hang in the global list itself (not inside another array's run), own no clipper list and clip nobody:
+         * clipper lists carry transform-node markers of their own (engine.cpp:1845-1947) */
+        auto top_level_elem = [&](int32_t srf, int32_t &prev_out) -> int32_t {
+            int32_t prev = QR_NULL;
+            for (int32_t e = clist_w; e != QR_NULL; )
+            {
+                const qr_elem &el = E_w[(size_t)e];
+                if (el.simd == srf && el.data == QR_NULL) { prev_out = prev; return e; }
+                if (el.data != QR_NULL)
+                {
+                    /* an array element: its run [next .. data] is not top level -- skip behind it */
+                    for (int32_t m = el.next; m != QR_NULL; m = E_w[(size_t)m].next)
+                    {
+                        if (E_w[(size_t)m].simd == srf) return QR_NULL - 1;
+                        if (m == el.data) break;
+                    }
+                    prev = el.data; e = E_w[(size_t)el.data].next;
+                    continue;
+                }
+                prev = e; e = el.next;
+            }
+            return QR_NULL - 1;
+        };
+        auto clips_or_is_clipped = [&](int32_t srf) {
+            if (S_w[(size_t)srf].clip != QR_NULL) return true;
+            for (size_t q = 0; q < S_w.size(); q++)
+                for (int32_t e = S_w[q].clip; e != QR_NULL; e = E_w[(size_t)e].next)
+                    if (E_w[(size_t)e].simd == srf) return true;
+            return false;
+        };
+        /* vanished transform nodes: the array's element leaves the list, its members stay where they are */
+        std::sort(died_of.begin(), died_of.end());
+        for (size_t q = 0; q < died_of.size(); q++)
+        {
+            if (q > 0 && died_of[q].first == died_of[q - 1].first) continue;
+            const int32_t rec = next[died_of[q].first].srf;
+            int32_t prev = QR_NULL, te = QR_NULL;
+            for (int32_t e = clist_w; e != QR_NULL; prev = e, e = E_w[(size_t)e].next)
+                if (E_w[(size_t)e].simd == rec && E_w[(size_t)e].data != QR_NULL) { te = e; break; }
+            if (te == QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": its transform-node element is not in the global list's top level");
+            for (int32_t m = E_w[(size_t)te].next; ; m = E_w[(size_t)m].next)
+            {
+                if (m == QR_NULL || E_w[(size_t)m].data != QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": nested arrays under a vanishing transform node");
+                if (clips_or_is_clipped(E_w[(size_t)m].simd)) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": a member takes part in custom clipping");
+                if (m == E_w[(size_t)te].data) break;
+            }
+            if (prev == QR_NULL) clist_w = E_w[(size_t)te].next; else E_w[(size_t)prev].next = E_w[(size_t)te].next;
+        }
+        /* new transform nodes: a record (rt_Array's s_srf as rt_Node::update_fields fills it, object.cpp:813-843: tag -1, no
+         * solver, its own transform node) and an element in front of the members, which move together behind it */
+        std::sort(born_of.begin(), born_of.end());
+        for (size_t q = 0; q < born_of.size(); )
+        {
+            const int arr = born_of[q].first;
+            size_t q1 = q;
+            while (q1 < born_of.size() && born_of[q1].first == arr) q1++;
+            qr_surface rec; memset(&rec, 0, sizeof(rec));
+            rec.c_def = 0xFFFFFFFFu; rec.smask = 0x80000000u; rec.d_eps = 1e-11f; rec.t_eps = 1e-7f;       /* RT_CULL_THRESHOLD / RT_CLIP_THRESHOLD-independent constants of every record: object.h:41-42 */
+            rec.srf_t[3] = QR_NODE_ARRAY; rec.clip = QR_NULL; rec.trnode = (int32_t)S_w.size();
+            rec.mat[0] = rec.mat[1] = QR_NULL; for (int k = 0; k < 4; k++) rec.lst[k] = QR_NULL;
+            const int32_t rec_ix = (int32_t)S_w.size();
+            S_w.push_back(rec);
+            nodes_w[(size_t)arr].srf = rec_ix;
+            /* unlink the members (list order kept), then link [array element, members...] where the first one stood */
+            std::vector<int32_t> mem;
+            int32_t anchor_prev = QR_NULL; bool have_anchor = false;
+            std::vector<std::pair<int32_t, int32_t>> found;         /* (position in the list, element) */
+            for (size_t k = q; k < q1; k++)
+            {
+                const int32_t srf = next[born_of[k].second].srf;
+                if (clips_or_is_clipped(srf)) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(born_of[k].second) + ": takes part in custom clipping under a new transform node");
+                int32_t pv = QR_NULL;
+                const int32_t e = top_level_elem(srf, pv);
+                if (e < QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(born_of[k].second) + ": not in the global list's top level (nested arrays need the engine's insert)");
+                int32_t posn = 0; for (int32_t w = clist_w; w != e; w = E_w[(size_t)w].next) posn++;
+                found.push_back(std::make_pair(posn, e));
+            }
+            std::sort(found.begin(), found.end());
+            for (size_t k = 0; k < found.size(); k++)
+            {
+                int32_t pv = QR_NULL;
+                for (int32_t w = clist_w; w != found[k].second; w = E_w[(size_t)w].next) pv = w;
+                if (!have_anchor) { anchor_prev = pv; have_anchor = true; }
+                if (pv == QR_NULL) clist_w = E_w[(size_t)found[k].second].next; else E_w[(size_t)pv].next = E_w[(size_t)found[k].second].next;
+                mem.push_back(found[k].second);
+            }
+            qr_elem te; te.simd = rec_ix; te.kind = 0; te.data = mem.back(); te.next = mem.front();
+            const int32_t te_ix = (int32_t)E_w.size();
+            E_w.push_back(te);
+            const int32_t after = anchor_prev == QR_NULL ? clist_w : E_w[(size_t)anchor_prev].next;
+            for (size_t k = 0; k + 1 < mem.size(); k++) E_w[(size_t)mem[k]].next = mem[k + 1];
+            E_w[(size_t)mem.back()].next = after;
+            if (anchor_prev == QR_NULL) clist_w = te_ix; else E_w[(size_t)anchor_prev].next = te_ix;
+            q = q1;
+        }
+        next = nodes_w.data();
+    }
+
+    /* the snapshot that is patched: a copy of the input, or -- when records and elements were added -- a re-serialised one */
+    std::vector<uint8_t> out;
+    qr_header hdr_w = *v.hdr;
+    if (!restructure) out.assign((const uint8_t *)blob, (const uint8_t *)blob + v.hdr->total_bytes);
+    else
+    {
+        auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        size_t off = a16(sizeof(qr_header));
+        hdr_w.header_bytes = sizeof(qr_header);
+        hdr_w.n_srf = (uint32_t)S_w.size(); hdr_w.n_elm = (uint32_t)E_w.size();
+        hdr_w.off_frame = (uint32_t)off;  off = a16(off + sizeof(qr_frame));
+        hdr_w.off_srf = (uint32_t)off;    off = a16(off + S_w.size() * sizeof(qr_surface));
+        hdr_w.off_mat = (uint32_t)off;    off = a16(off + (size_t)hdr_w.n_mat * sizeof(qr_material));
+        hdr_w.off_lgt = (uint32_t)off;    off = a16(off + (size_t)hdr_w.n_lgt * sizeof(qr_light));
+        hdr_w.off_elm = (uint32_t)off;    off = a16(off + E_w.size() * sizeof(qr_elem));
+        hdr_w.off_tiles = (uint32_t)off;  off = a16(off + (size_t)hdr_w.n_tiles * 4);
+        hdr_w.off_texels = (uint32_t)off; off = a16(off + (size_t)hdr_w.n_texels * 4);
+        hdr_w.total_bytes = (uint32_t)off;
+        out.assign(off, 0);
+        memcpy(out.data(), &hdr_w, sizeof(hdr_w));
+        memcpy(out.data() + hdr_w.off_frame, v.frame, sizeof(qr_frame));
+        memcpy(out.data() + hdr_w.off_srf, S_w.data(), S_w.size() * sizeof(qr_surface));
+        if (hdr_w.n_mat) memcpy(out.data() + hdr_w.off_mat, v.mat, (size_t)hdr_w.n_mat * sizeof(qr_material));
+        if (hdr_w.n_lgt) memcpy(out.data() + hdr_w.off_lgt, v.lgt, (size_t)hdr_w.n_lgt * sizeof(qr_light));
+        memcpy(out.data() + hdr_w.off_elm, E_w.data(), E_w.size() * sizeof(qr_elem));
+        if (hdr_w.n_tiles) memcpy(out.data() + hdr_w.off_tiles, v.tiles, (size_t)hdr_w.n_tiles * 4);
+        if (hdr_w.n_texels) memcpy(out.data() + hdr_w.off_texels, v.texels, (size_t)hdr_w.n_texels * 4);
+        ((qr_frame *)(out.data() + hdr_w.off_frame))->clist = clist_w;
+    }
+    qr_surface *S = (qr_surface *)(out.data() + hdr_w.off_srf);
+    qr_light *L = (qr_light *)(out.data() + hdr_w.off_lgt);
+    qr_frame *F = (qr_frame *)(out.data() + hdr_w.off_frame);
     for (int i = 0; i < n; i++)
     {
         const qr_node &nd = next[i];
@@ -386,7 +543,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     {
         /* clip boxes of surfaces and the records of arrays' bounding volumes for the new transforms (qr_hbounds.cpp) */
         std::vector<qr_node_bounds> nb((size_t)n);
-        rc = qr_hierarchy_bounds(blob, size, next, n, opts, nb.data());
+        rc = restructure ? qr_hierarchy_bounds(out.data(), out.size(), next, n, opts, nb.data()) : qr_hierarchy_bounds(blob, size, next, n, opts, nb.data());
         if (rc != QR_OK) return rc;
         for (int i = 0; i < n; i++)
         {
@@ -453,8 +610,8 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     }
     if (flags & QR_HIER_RESET_TILES)
     {
-        int32_t *T = (int32_t *)(out.data() + v.hdr->off_tiles);
-        for (uint32_t k = 0; k < v.hdr->n_tiles; k++) T[k] = F->clist;
+        int32_t *T = (int32_t *)(out.data() + hdr_w.off_tiles);
+        for (uint32_t k = 0; k < hdr_w.n_tiles; k++) T[k] = F->clist;
     }
     void *p = malloc(out.size());
     if (p == nullptr) return qr_fail(QR_ERR_NOMEM, "out of memory");

@@ -24,6 +24,9 @@ EXTRA = {
     "demo01_160_t2500": ("demo01", ["-t", "2500"]),                             # base: demo01_160_t12345
     "demo01_160_gf_t2500": ("demo01", ["--gamma", "--fresnel", "-t", "2500"]),  # base: demo01_160_gf_t5000
     "demo03_160_t3000": ("demo03", ["-t", "3000"]),                             # base: demo03_160 (camera animator only)
+    # round 4: targets for the t = 0 snapshots -- the light's array starts rotating there, i.e. the SET of transform nodes changes
+    "demo02_160_t4000": ("demo02", ["-t", "4000"]),                             # base: demo02_160
+    "demo03_160_t7000": ("demo03", ["-t", "7000"]),                             # base: demo03_160
 }
 
 

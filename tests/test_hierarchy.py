@@ -30,6 +30,13 @@ ANIMATED = [
     ("demo01_160_gf_t5000", "demo01_160_gf_t2500", "tree"),
     ("demo02_160_gf_t5000", "demo02_160_t7777_gf", "golden"),
     ("demo03_160", "demo03_160_t3000", "tree"),
+    # round 4: the SET of transform nodes changes between the two times -- the light's array of demo scenes 1 and 2 leaves its
+    # right angle at t > 0 and becomes the transform node of its bulb (a record and a list element are created), or returns
+    ("demo01_160", "demo01_160_t2500", "tree"),
+    ("demo01_160", "demo01_160_t12345", "golden"),
+    ("demo01_160_t12345", "demo01_160", "golden"),
+    ("demo02_160", "demo02_160_t4000", "tree"),
+    ("demo03_160", "demo03_160_t7000", "tree"),
 ]
 
 
@@ -275,16 +282,88 @@ def test_gpu_animated_snapshot_gives_the_reference_frame_of_that_time(qr, base_n
     assert (frame == _target_frame(target_name, where)).all()
 
 
+def _snapshot_view(blob):
+    import struct
+    f = struct.unpack_from("<4I6I7I5I", blob, 0)
+    n_srf, n_elm, o_frame, o_srf, o_elm = f[4], f[7], f[10], f[11], f[14]
+    S = np.frombuffer(blob, dtype=np.uint32, count=n_srf * 64, offset=o_srf).reshape(n_srf, 64)
+    E = np.frombuffer(blob, dtype=np.int32, count=n_elm * 4, offset=o_elm).reshape(n_elm, 4)
+    return S, E, int(np.frombuffer(blob, dtype=np.int32, count=64, offset=o_frame)[38])
+
+
+@pytest.mark.parametrize("base_name,target_name", [("demo01_160", "demo01_160_t12345"), ("demo01_160_t12345", "demo01_160")])
+def test_changing_set_of_transform_nodes_gives_the_engines_records_and_list_order(qr, base_name, target_name):
+    """An array that starts (or stops) being a transform node: qr_hierarchy_apply creates (drops) its record and its element
+    of the global list.  Against the ENGINE's snapshot of the target time, node by node: every transform field of every record
+    -- the new transform node's included -- and the camera list member for member, array elements and kinds included."""
+    tb, base = load_tree(qr, base_name)
+    _, tgt = load_tree(qr, target_name)
+    nxt = base.copy()
+    for f in ("scl", "rot", "pos"):
+        nxt[f] = tgt[f]
+    # QR_HIER_BOUNDS: the members' boxes are expressed in the new transform node's space (min / max relative to the position)
+    patched = qr.hierarchy_apply(load_blob(base_name), nxt, tb["opts"], camera=tb["camera"], base=base,
+                                 flags=qr.HIER_RESET_TILES | qr.HIER_BOUNDS)
+    Sp, Ep, cp = _snapshot_view(patched)
+    Se, Ee, ce = _snapshot_view(load_blob(target_name))
+    rec_p = {i: int(base[i]["srf"]) for i in range(len(base)) if base[i]["srf"] >= 0}
+    born = [i for i in range(len(tgt)) if tgt[i]["srf"] >= 0 and base[i]["srf"] < 0]
+    assert len(born) <= 1
+    for i in born:
+        rec_p[i] = len(Sp) - 1                      # the record apply appended
+    assert len(Sp) == _snapshot_view(load_blob(base_name))[0].shape[0] + len(born)
+    # qr_surface words: pos 0-2, c_def 3, min 4-6, minmax_t 7, max 8-10, conic 11, tci 12-14, has_trm 15, tcj 16-18, shift 19,
+    # tck 20-22, axes 23, sci 24-27, scj 28-30, smask 31, d_eps 32, t_eps 33, srf_t 34-37, (clip 38), trnode 39
+    words = list(range(0, 38))
+    node_of_e = {int(tgt[i]["srf"]): i for i in range(len(tgt)) if tgt[i]["srf"] >= 0}
+    node_of_p = {r: i for i, r in rec_p.items()}
+    for i in range(len(tgt)):
+        if tgt[i]["srf"] < 0 or i not in rec_p:
+            continue
+        a, b = Sp[rec_p[i]], Se[int(tgt[i]["srf"])]
+        assert (a[words] == b[words]).all(), (i, [w for w in words if a[w] != b[w]])
+        ta, tb_ = int(a.view(np.int32)[39]), int(b.view(np.int32)[39])
+        assert (ta < 0) == (tb_ < 0) and (ta < 0 or node_of_p[ta] == node_of_e[tb_]), i      # the same transform node
+
+    def chain(S, E, head, node_of):
+        out, e = [], head
+        while e != -1:
+            simd, data, nxt_, kind = (int(x) for x in E[e])
+            out.append((node_of.get(simd, ("record", simd)), data != -1, kind))
+            e = nxt_
+        return out
+    ours, engines = chain(Sp, Ep, cp, node_of_p), chain(Se, Ee, ce, node_of_e)
+    assert ours == engines
+    # the array element's run ends at the same member
+    def last_of(S, E, head, node_of):
+        e = head
+        while e != -1:
+            if E[e][1] != -1:
+                return node_of[int(E[int(E[e][1])][0])]
+            e = int(E[e][2])
+        return None
+    assert last_of(Sp, Ep, cp, node_of_p) == last_of(Se, Ee, ce, node_of_e)
+
+
 def test_updates_outside_the_scope_are_refused(qr):
-    """demo01 at t = 0: the light's array is not rotated yet; at t = 2500 it is a transform node, the bulb's record needs a
-    trnode the snapshot has no record and no list element for -- the engine rebuilds its lists there, apply refuses."""
+    """What apply still refuses.  A changing set of transform nodes needs the node tables of both times (`base`) and the tile
+    lists reset; members that sit inside another array's run of the list would need the engine's ordered insert
+    (engine.cpp:1116-1645): demo scene 2's frame table (nested arrays with bounding volumes) turned by 10 degrees."""
     t0, base = load_tree(qr, "demo01_160")
     _, tgt = load_tree(qr, "demo01_160_t2500")
     nxt = base.copy()
     for f in ("scl", "rot", "pos"):
         nxt[f] = tgt[f]
     with pytest.raises(qr.QrError, match="transform node"):
-        qr.hierarchy_apply(load_blob("demo01_160"), nxt, t0["opts"], camera=t0["camera"], base=base)
+        qr.hierarchy_apply(load_blob("demo01_160"), nxt, t0["opts"], camera=t0["camera"])               # no base table
+    with pytest.raises(qr.QrError, match="QR_HIER_RESET_TILES"):
+        qr.hierarchy_apply(load_blob("demo01_160"), nxt, t0["opts"], camera=t0["camera"], base=base)    # tile lists would go stale
+    t2, b2 = load_tree(qr, "demo02_160")
+    arr = next(i for i in range(len(b2)) if b2[i]["tag"] == -1 and b2[i]["bvb"] >= 0 and b2[i]["parent"] >= 0)
+    turned = b2.copy()
+    turned[arr]["rot"][2] += 10.0
+    with pytest.raises(qr.QrError, match="transform node|top level|nested|clipping"):
+        qr.hierarchy_apply(load_blob("demo02_160"), turned, t2["opts"], camera=t2["camera"], base=b2, flags=qr.HIER_RESET_TILES | qr.HIER_BOUNDS)
     # a right-angle turn of a clipped surface changes its axis mapping: the clip box would have to be rebuilt
     tb, b13 = load_tree(qr, "test13_160")
     k = next(i for i in range(len(b13)) if 0 <= b13[i]["tag"] < 9 and b13[i]["srf"] >= 0)
