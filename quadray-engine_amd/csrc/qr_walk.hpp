@@ -1468,6 +1468,15 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
 #ifndef QR_DDA_SPLIT_MAXOWN
 #define QR_DDA_SPLIT_MAXOWN 32
 #endif
+#ifndef QR_DDA_RESPLIT
+#define QR_DDA_RESPLIT 1        /* stretches are halved again while the walk runs, whenever enough lanes idle (0: only the split at the start) */
+#endif
+#ifndef QR_DDA_RESPLIT_IDLE
+#define QR_DDA_RESPLIT_IDLE 12     /* (4: -1.6 %, 8: -0.6 %, 32: -3 % against 12 on config 5) */
+#endif
+#ifndef QR_DDA_RESPLIT_CELLS
+#define QR_DDA_RESPLIT_CELLS 2  /* a lane only gives away the far half of a stretch of at least this many cells */
+#endif
 #ifndef QR_DDA_SPLIT
 #define QR_DDA_SPLIT 1    /* rays of a sparse wave are cut into segments marched by idle lanes */
 #endif
@@ -1525,8 +1534,27 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
     u32 p_op = 0, p_srf = 0, p_pos = 0;
     /* DDA state */
     float tmx = 0, tmy = 0, tmz = 0, tdx = 0, tdy = 0, tdz = 0, t_end = 0;
+    float t_far = 0;                            /* finite far end of this lane's stretch: its segment's end or the grid's exit */
     int ix = 0, iy = 0, iz = 0;
     bool march = false;                         /* in the grid (pass 1) */
+    /* first cell and DDA increments of a stretch of the current ray `cr` that starts at t0 */
+    auto enter_at = [&](float t0) {
+        const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
+        const float ox = cr.org.x - u2f(g0.x), oy = cr.org.y - u2f(g0.y), oz = cr.org.z - u2f(g0.z);
+        const float rx = __builtin_amdgcn_rcpf(cr.dir.x), ry = __builtin_amdgcn_rcpf(cr.dir.y), rz = __builtin_amdgcn_rcpf(cr.dir.z);
+        const float px = ox + cr.dir.x * t0, py = oy + cr.dir.y * t0, pz = oz + cr.dir.z * t0;
+        ix = cvt_floor(px * u2f(g1.x)); iy = cvt_floor(py * u2f(g1.y)); iz = cvt_floor(pz * u2f(g1.z));
+        ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix); iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy); iz = iz < 0 ? 0 : (iz >= nz ? nz - 1 : iz);
+        const float inf = __builtin_inff();
+        tdx = cr.dir.x == 0.0f ? inf : u2f(g2.x) * __builtin_fabsf(rx);
+        tdy = cr.dir.y == 0.0f ? inf : u2f(g2.y) * __builtin_fabsf(ry);
+        tdz = cr.dir.z == 0.0f ? inf : u2f(g2.z) * __builtin_fabsf(rz);
+        tmx = cr.dir.x == 0.0f ? inf : ((float)(ix + (cr.dir.x > 0.0f ? 1 : 0)) * u2f(g2.x) - ox) * rx;
+        tmy = cr.dir.y == 0.0f ? inf : ((float)(iy + (cr.dir.y > 0.0f ? 1 : 0)) * u2f(g2.y) - oy) * ry;
+        tmz = cr.dir.z == 0.0f ? inf : ((float)(iz + (cr.dir.z > 0.0f ? 1 : 0)) * u2f(g2.z) - oz) * rz;
+        const u32 ci = g1.w + (u32)((iz * ny + iy) * nx + ix) * 4u;
+        rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+    };
     P.key[lane] = ((unsigned long long)f2u(r.tmax) << 32) | 0xFFFFFFFFull;
     __syncthreads();
 #ifdef QR_STATS
@@ -1602,21 +1630,8 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
                 const float dt = (t_out - t_in) * (1.0f / (float)K);
                 const float t0 = seg == 0 ? t_in : t_in + dt * (float)seg;
                 t_end = seg == K - 1 ? __builtin_inff() : t_in + dt * (float)(seg + 1);
-                const int nx = (int)(g0.w & 255u), ny = (int)((g0.w >> 8) & 255u), nz = (int)((g0.w >> 16) & 255u);
-                const float ox = cr.org.x - u2f(g0.x), oy = cr.org.y - u2f(g0.y), oz = cr.org.z - u2f(g0.z);
-                const float rx = __builtin_amdgcn_rcpf(cr.dir.x), ry = __builtin_amdgcn_rcpf(cr.dir.y), rz = __builtin_amdgcn_rcpf(cr.dir.z);
-                const float px = ox + cr.dir.x * t0, py = oy + cr.dir.y * t0, pz = oz + cr.dir.z * t0;
-                ix = cvt_floor(px * u2f(g1.x)); iy = cvt_floor(py * u2f(g1.y)); iz = cvt_floor(pz * u2f(g1.z));
-                ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix); iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy); iz = iz < 0 ? 0 : (iz >= nz ? nz - 1 : iz);
-                const float inf = __builtin_inff();
-                tdx = cr.dir.x == 0.0f ? inf : u2f(g2.x) * __builtin_fabsf(rx);
-                tdy = cr.dir.y == 0.0f ? inf : u2f(g2.y) * __builtin_fabsf(ry);
-                tdz = cr.dir.z == 0.0f ? inf : u2f(g2.z) * __builtin_fabsf(rz);
-                tmx = cr.dir.x == 0.0f ? inf : ((float)(ix + (cr.dir.x > 0.0f ? 1 : 0)) * u2f(g2.x) - ox) * rx;
-                tmy = cr.dir.y == 0.0f ? inf : ((float)(iy + (cr.dir.y > 0.0f ? 1 : 0)) * u2f(g2.y) - oy) * ry;
-                tmz = cr.dir.z == 0.0f ? inf : ((float)(iz + (cr.dir.z > 0.0f ? 1 : 0)) * u2f(g2.z) - oz) * rz;
-                const u32 ci = g1.w + (u32)((iz * ny + iy) * nx + ix) * 4u;
-                rp = *(const QR_CONST u32 *)(B + ci); rend = *(const QR_CONST u32 *)(B + ci + 4u);
+                t_far = seg == K - 1 ? t_out : t_end;
+                enter_at(t0);
             }
         }
         for (;;)
@@ -1624,6 +1639,61 @@ __device__ __forceinline__ void walk_dda(BaseP B, bool active, const Ray &r, Hit
             const lm_t pend = LM(p_op != 0);
             const lm_t adv = (pass == 0 ? LM(rp < rend) : LM(march)) & ~pend;
             if ((adv | pend) == 0) break;
+#if QR_DDA_RESPLIT
+            if (pass == 1)
+            {
+                /* Stretches end at very different times (a hit right behind the start, or a march through the whole grid): as
+                 * soon as QR_DDA_RESPLIT_IDLE lanes have nothing to march, lanes with a long stretch ahead hand its far half to
+                 * them -- the walk lasts as long as its longest stretch, and that is halved.  The same split as the one at the
+                 * start (the cell around the cut is looked at from both sides, hits meet in LDS as the minimum of depth and
+                 * original cell), only later. */
+                const lm_t idle = ~(LM(march) | pend);
+                const float cur_t = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+                const float lim = __builtin_fminf(t_far, __builtin_fminf(w.tbuf, u2f(((const volatile u32 *)&P.key[owner])[1])));
+                const bool can_give = march && p_op == 0 && (lim - cur_t) > (float)QR_DDA_RESPLIT_CELLS * __builtin_fminf(tdx, __builtin_fminf(tdy, tdz));
+                const lm_t givers = LM(can_give);
+                if (givers != 0 && __popcll(idle) >= QR_DDA_RESPLIT_IDLE)
+                {
+                    const int n_g = __popcll(givers), n_i = __popcll(idle);
+                    const int rank_g = lanes_below(givers), rank_i = lanes_below(idle);
+                    if (can_give && rank_g < n_i)
+                    {
+                        const float mid = 0.5f * (cur_t + lim);
+                        P.give[rank_g] = u32x4{(u32)lane, f2u(mid), f2u(t_end), f2u(t_far)};
+                        t_end = mid; t_far = mid;
+                    }
+                    __syncthreads();
+                    const bool tk = lane_of(idle) && rank_i < n_g;
+                    const u32x4 gv = P.give[tk ? rank_i : 0];
+                    const int src = tk ? (int)gv.x : lane;
+                    const float f_ox = __shfl(cr.org.x, src), f_oy = __shfl(cr.org.y, src), f_oz = __shfl(cr.org.z, src);
+                    const float f_dx = __shfl(cr.dir.x, src), f_dy = __shfl(cr.dir.y, src), f_dz = __shfl(cr.dir.z, src);
+                    const float f_tmn = __shfl(cr.tmin, src), f_tb = __shfl(w.tbuf, src);
+                    const u32 f_osf = (u32)__shfl((int)cr.osrf, src); const int f_ofl = __shfl(cr.oflg, src);
+                    const float f_px = __shfl(cr.ploc.x, src), f_py = __shfl(cr.ploc.y, src), f_pz = __shfl(cr.ploc.z, src);
+                    const u32 f_lo = (u32)__shfl((int)lo, src), f_bp = (u32)__shfl((int)best_pos, src);
+                    const int f_own = __shfl(owner, src);
+                    if (tk)
+                    {
+                        owner = f_own; march = true;
+                        cr.org = {f_ox, f_oy, f_oz}; cr.dir = {f_dx, f_dy, f_dz}; cr.tmin = f_tmn; cr.tmax = f_tb;
+                        cr.osrf = f_osf; cr.oflg = f_ofl; cr.ploc = {f_px, f_py, f_pz};
+                        dd = f_dx * f_dx + f_dy * f_dy + f_dz * f_dz;
+                        dlen = __builtin_amdgcn_sqrtf(dd) * 1.000001f;
+                        dde = dd * 1e-5f;
+                        w.tbuf = f_tb; w.tbd = f_tb * dd; w.resume = 0;
+                        best_pos = f_bp; lh.srf = 0; last0 = 0; last1 = 0;
+                        lo = f_lo;
+                        g0 = *(const QR_CONST u32x4 *)(B + (lo - 64u)); g1 = *(const QR_CONST u32x4 *)(B + (lo - 48u));
+                        g2 = *(const QR_CONST u32x4 *)(B + (lo - 32u)); g3 = *(const QR_CONST u32x4 *)(B + (lo - 16u));
+                        t_end = u2f(gv.z); t_far = u2f(gv.w);
+                        enter_at(u2f(gv.y));
+                    }
+                    __syncthreads();
+                    continue;
+                }
+            }
+#endif
             if (adv != 0 && __popcll(pend) < QR_DDA_BATCH)
             {
 #ifdef QR_STATS
