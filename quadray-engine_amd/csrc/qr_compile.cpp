@@ -666,8 +666,24 @@ struct Builder
             }
             want_dda = ok && n_small >= dda_min;
         }
-        const uint32_t base = alloc((size_t)(ne + 1) * sizeof(CCell) + (want_dda ? sizeof(CDda) : 0), 64);
-        const uint32_t off = base + (want_dda ? (uint32_t)sizeof(CDda) : 0u);
+        /* Lists the per-lane walk with hand-over may take (world-space cells only, no clipper program) carry their LENGTH in the
+         * word in front of the program -- in a cell of their own, or in the grid record's spare word: (bytes of cells in front of
+         * the END cell) | 1 when no cell is a bounding volume (every multiple of 32 bytes is then a cell boundary).  walk_pool
+         * cuts such a flat list in halves for idle lanes (qr_walk.hpp); a list program ends with an END cell, so without this
+         * word a lane knows where its range ends only when it gets there. */
+        bool pre_world = true, pre_div = true; int pre_bv = 0;
+        for (int i = 0; i < n; i++)
+        {
+            if (!ch[i].emit) continue;
+            if ((ch[i].op & QR_OPT_TRNODE) || (ch[i].op & QR_OPF_LOCAL)) pre_world = false;
+            if (ch[i].op & QR_OPF_CLIP) pre_div = false;
+            if (ch[i].op & QR_OPT_BV) pre_bv++;
+        }
+        const bool want_len = pre_world && pre_div;
+        const size_t front = want_dda ? sizeof(CDda) : (want_len ? sizeof(CCell) : 0);
+        const uint32_t base = alloc((size_t)(ne + 1) * sizeof(CCell) + front, 64);
+        const uint32_t off = base + (uint32_t)front;
+        if (want_len) *at<uint32_t>(off - 4u) = (uint32_t)ne * (uint32_t)sizeof(CCell) | (pre_bv == 0 ? 1u : 0u);
         list_off[head] = off;
         for (int i = 0; i < n; i++)
         {
@@ -838,6 +854,7 @@ struct Builder
         memcpy(at<uint32_t>(g.cells), cnt.data(), (n_cells + 1) * 4);
         g.refs = alloc((size_t)(n_refs + 2) * sizeof(CCell), 32);        /* + slack: the walk loads 32 bytes at its cursor */
         if (n_refs) memcpy(at<CCell>(g.refs), refs.data(), (size_t)n_refs * sizeof(CCell));
+        g.pad[1] = *at<uint32_t>(off - 4u);                            /* the list's length word (compile_list) lives in the record's last word */
         *at<CDda>(rec_off) = g;
         n_dda++;
     }
@@ -1413,7 +1430,7 @@ int qr_program_verify(const QrProgram &p, std::string &err)
     auto check_list = [&](uint32_t off) -> const char * {
         if (off == 0) return nullptr;
         if (off & 8u) return "list offset carries unknown flag bits";
-        const bool world = (off & QR_LISTF_WORLD) != 0, dda = (off & QR_LISTF_DDA) != 0;
+        const bool world = (off & QR_LISTF_WORLD) != 0, dda = (off & QR_LISTF_DDA) != 0, div_ok = (off & QR_LISTF_DIV) != 0;
         off &= ~31u;
         if (off < p.off_lists || (size_t)off + 32 > limit) return "list offset out of range";
         if (slot[off / 32] & 1) return (((slot[off / 32] & 4) != 0) == world && ((slot[off / 32] & 8) != 0) == dda) ? nullptr : "list referenced with different flags";
@@ -1426,6 +1443,14 @@ int qr_program_verify(const QrProgram &p, std::string &err)
             slot[o / 32] |= 2;
             if (c->op == 0) { end_cell = o; break; }
             o += (c->op & QR_OPT_BV) ? 64 : 32;
+        }
+        if (world && div_ok)
+        {
+            /* the length word in front of the program: what walk_pool cuts ranges by */
+            uint32_t lw; memcpy(&lw, b.data() + off - 4u, 4);
+            bool any_bv = false;
+            for (uint32_t q = off; q < end_cell; ) { const CCell *cq = (const CCell *)(b.data() + q); const bool bvq = (cq->op & QR_OPT_BV) != 0; any_bv = any_bv || bvq; q += bvq ? 64 : 32; }
+            if ((lw & ~31u) != end_cell - off || (lw & 30u) != 0 || ((lw & 1u) != 0) != !any_bv) return "list length word";
         }
         for (o = off; o < end_cell; )
         {

@@ -1173,6 +1173,15 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
 #ifndef QR_POOL_MIN_IDLE
 #define QR_POOL_MIN_IDLE 12     /* hand-over round as soon as this many lanes have nothing to do (2: +2 %, 6: +1.5 % frame time) */
 #endif
+#ifndef QR_POOL_FLAT
+#define QR_POOL_FLAT 1             /* flat lists are cut in halves for idle lanes (0: hand-over only at the boundaries bounding volumes give) */
+#endif
+#ifndef QR_POOL_FLAT_MIN_BYTES
+#define QR_POOL_FLAT_MIN_BYTES 128u    /* a flat range of at least four cells gives its far half away */
+#endif
+#ifndef QR_POOL_FLAT_MIN_IDLE
+#define QR_POOL_FLAT_MIN_IDLE 8
+#endif
 #ifndef QR_POOL_MIN_BYTES
 #define QR_POOL_MIN_BYTES 384u  /* a lane only gives a range of at least this many bytes of cells away */
 #endif
@@ -1255,6 +1264,18 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
     u32 pos = active ? (r.list & ~31u) : 0u;    /* 0: nothing to walk */
     u32 iend = 0xFFFFFFFFu;                     /* end of the range; the first range of a ray ends at the END cell */
     u32 give = 0;
+#if QR_POOL_FLAT
+    /* a FLAT list (no bounding-volume cell: every 32 bytes a cell) tells its length in the word in front of it (qr_compile.cpp):
+     * its range can be cut anywhere, and is -- in halves, whenever lanes idle (round 4: the shadow lists of hits on small
+     * objects are ten such cells, and a walk lasted as long as its slowest ray's ten) */
+    bool flat = false;
+    if (pos != 0)
+    {
+        const u32 lw = *(const QR_CONST u32 *)(B + (pos - 4u));
+        flat = (lw & 1u) != 0;
+        if (flat) iend = pos + (lw & ~31u);
+    }
+#endif
     u32 p_op = 0, p_srf = 0, p_pos = 0;         /* the candidate cell the lane stands on (p_op == 0: none) */
     bool busy = active;
 #if defined(QR_STATS) && defined(QR_GUARD)
@@ -1294,16 +1315,30 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
         if (work == 0) break;
 
         /* ---- hand-over ---- */
+#if QR_POOL_FLAT
+        /* flat range: the boundary is its middle cell */
+        if (flat && pos != 0 && p_op == 0) give = (iend - pos) >= QR_POOL_FLAT_MIN_BYTES ? pos + (((iend - pos) >> 6) << 5) : 0u;
+        const bool can_give = pos != 0 && give > pos && (iend - give) >= (flat ? 32u : QR_POOL_MIN_BYTES);
+        const lm_t givers = LM(can_give);
+        const lm_t idle = ~work;
+        if (givers != 0 && __popcll(idle) >= (__popcll(LM(can_give && flat)) != 0 ? QR_POOL_FLAT_MIN_IDLE : QR_POOL_MIN_IDLE))
+        {
+#else
         const bool can_give = pos != 0 && give > pos && (iend - give) >= QR_POOL_MIN_BYTES;
         const lm_t givers = LM(can_give);
         const lm_t idle = ~work;
         if (givers != 0 && __popcll(idle) >= QR_POOL_MIN_IDLE)
         {
+#endif
             const int n_g = __popcll(givers), n_i = __popcll(idle);
             const int rank_g = lanes_below(givers), rank_i = lanes_below(idle);
             if (can_give && rank_g < n_i)
             {
+#if QR_POOL_FLAT
+                P.give[rank_g] = u32x4{(u32)owner, give, iend, flat ? 1u : 0u};
+#else
                 P.give[rank_g] = u32x4{(u32)owner, give, iend, 0u};
+#endif
                 iend = give; give = 0;
             }
             __syncthreads();
@@ -1319,6 +1354,9 @@ __device__ __forceinline__ void walk_pool(BaseP B, bool active, const Ray &r, Hi
             if (tk)
             {
                 owner = src; pos = g.y; iend = g.z; give = 0; busy = true;
+#if QR_POOL_FLAT
+                flat = g.w != 0u;
+#endif
                 QR_G(g_prev = g.z; g_how = 8;)
                 cr.org = {ox, oy, oz}; cr.dir = {dx, dy, dz}; cr.tmin = tmn; cr.tmax = tmx;
                 cr.osrf = osf; cr.oflg = ofl; cr.ploc = {px, py, pz};
