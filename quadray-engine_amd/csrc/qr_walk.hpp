@@ -1167,6 +1167,12 @@ __device__ __forceinline__ void walk_div(BaseP B, bool active, const Ray &r, Hit
 #ifndef QR_INCOH_MIN
 #define QR_INCOH_MIN 3      /* lanes left when the leader's group is at most a third of them: walk per lane (measured 3 vs 12: -7 % frame time) */
 #endif
+#ifndef QR_INCOH_RATIO
+#define QR_INCOH_RATIO 3    /* per lane when the leader's group is at most QR_INCOH_DEN / QR_INCOH_RATIO of the lanes left */
+#endif
+#ifndef QR_INCOH_DEN
+#define QR_INCOH_DEN 1
+#endif
 #ifndef QR_POOL
 #define QR_POOL 1          /* 0: walk_div without hand-over (A/B) */
 #endif
@@ -1881,7 +1887,7 @@ __device__ __forceinline__ void traverse(BaseP B, bool active, bool coherent, co
         {
         const int n_left = __popcll(pending), n_mine = __popcll(mine);
         const lm_t can_div = pending & LM((r.list & QR_LISTF_DIV) != 0);
-        const bool incoherent = n_mine * 3 <= n_left && n_left >= QR_INCOH_MIN;
+        const bool incoherent = n_mine * QR_INCOH_RATIO <= n_left * QR_INCOH_DEN && n_left >= QR_INCOH_MIN;
         const bool long_list = !coherent && (head & QR_LISTF_LONG) != 0 && (head & QR_LISTF_DIV) != 0 && n_mine >= QR_LONG_MIN;
         if ((incoherent || long_list) && can_div != 0)
         {

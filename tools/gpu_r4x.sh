@@ -2,6 +2,6 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 python3 $R/tools/archive_src.py >/dev/null 2>&1 || true
 cd $R
-for rep in 1 2; do for L in libqrhip.so libqrhip_z_db24.so libqrhip_z_db32.so libqrhip_z_db8.so libqrhip_z_dd10.so libqrhip_z_dd16.so; do
-  QR_LIB=$R/quadray-engine_amd/$L python bench.py --workload synth10k_4320p --steps 30 --warmup 5 --no-cpu-baseline --repetitions 1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['value'],1), 'Mrays/s', 'isolated', round(d['roofline']['kernel_avg_ms'],4))" | tee -a $O/r4z_batch.txt
+for rep in 1 2; do for L in libqrhip.so libqrhip_q_r2.so libqrhip_q_r32.so libqrhip_q_r1.so libqrhip_q_r4.so; do
+  QR_LIB=$R/quadray-engine_amd/$L python bench.py --workload synth10k_4320p --steps 30 --warmup 5 --no-cpu-baseline --repetitions 1 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['value'],1), 'Mrays/s', 'isolated', round(d['roofline']['kernel_avg_ms'],4))" | tee -a $O/r4q_incoh.txt
 done; done
