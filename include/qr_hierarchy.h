@@ -27,7 +27,11 @@
  * light arrays of the demo scenes; qr_hierarchy_apply then creates (drops) the node's record and its element of the global
  * list, needs both node tables (`base`) and QR_HIER_RESET_TILES, and returns a LARGER snapshot.  Members inside another
  * array's run of the list, or clippers, would need the engine's ordered insert (engine.cpp:1116-1645, rtgeom.cpp:1244) and
- * are refused with QR_ERR_UNSUP naming the node.
+ * are refused with QR_ERR_UNSUP naming the node.  A SURFACE may start or stop being its OWN transform node (a right angle
+ * <-> any angle): its record takes / loses the matrix, no list element changes; refused while it takes part in custom
+ * clipping.  When a textured plane's axis scalers change with that (the scale moves into or out of the matrix), the texture
+ * scale and offset of its two materials follow (rt_Plane::update_fields, object.cpp:2893-2938) -- provided the base scalers
+ * are 1, where the material's own scale can be read back from its record exactly; otherwise QR_ERR_UNSUP.
  *
  * Plain C ABI; fp32 arithmetic in the reference's operation order: the results are bit-identical to the engine's
  * (tests/test_hierarchy.py, fixtures dumped from the engine by oracle/ref_driver.cpp --tree).

@@ -310,6 +310,8 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     if (rc != QR_OK) return qr_fail(rc, err);
     std::vector<qr_node_state> st((size_t)(n > 0 ? n : 0)), st0;
     std::vector<std::pair<int, int>> born_of, died_of;      /* (array node, member surface node): transform nodes that appear / vanish */
+    std::vector<int> self_of;                               /* surfaces that become / stop being their own transform node */
+    std::vector<int> plane_tex;                             /* planes whose axis scalers leave 1: texture scale / offset of their materials */
     rc = run_update(next, n, opts, st.data(), err);
     if (rc != QR_OK) return qr_fail(rc, err);
     const int n_srf = (int)v.hdr->n_srf, n_lgt = (int)v.hdr->n_lgt;
@@ -351,15 +353,39 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                                && st0[(size_t)t_new].trnode < 0;
                 const bool died = is_surface(next[i].tag) && t_new < 0 && t_old >= 0 && t_old != i && next[t_old].tag == QR_NODE_ARRAY
                                && next[t_old].srf >= 0 && st[(size_t)t_old].trnode < 0;
-                if (born) { born_of.push_back(std::make_pair(t_new, i)); continue; }
-                if (died) { died_of.push_back(std::make_pair(t_old, i)); continue; }
-                if (next[i].tag == QR_NODE_ARRAY && next[i].srf >= 0 && b.trnode != i && a.trnode == i) continue;   /* the array that stops: handled through its members */
-                return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
+                if (born) born_of.push_back(std::make_pair(t_new, i));
+                else if (died) died_of.push_back(std::make_pair(t_old, i));
+                /* a surface that becomes (or stops being) its OWN transform node: its record carries the matrix itself and the
+                 * lists hold no element for it -- only custom clipping would (its clippers' lists carry transform-node markers) */
+                const bool self = !born && !died && is_surface(next[i].tag) && ((t_old < 0 && t_new == i) || (t_new < 0 && t_old == i));
+                if (self) self_of.push_back(i);
+                const bool stops = next[i].tag == QR_NODE_ARRAY && next[i].srf >= 0 && b.trnode != i && a.trnode == i;   /* the array that stops: handled through its members */
+                if (!born && !died && !self && !stops)
+                    return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
             }
             if (has_record && !(flags & QR_HIER_BOUNDS) &&
                 (!same_bits(a.map, b.map, sizeof(a.map)) || !same_bits(a.sgn, b.sgn, sizeof(a.sgn)) || !same_bits(a.scl, b.scl, sizeof(a.scl))))
                 return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": axis mapping or scalers change (clip boxes would; QR_HIER_BOUNDS recomputes them)");
             moved[(size_t)i] = !same_bits(a.mtx, b.mtx, sizeof(a.mtx));
+            if (has_record && next[i].tag == QR_TAG_PLANE)
+            {
+                /* a plane's axis scalers enter the texture scale and offset of its two materials (rt_Plane::update_fields,
+                 * object.cpp:2893-2938): asc = scl[mp_i], scl[mp_j].  The material's own scale and position are not in the
+                 * snapshot; they can be read back from its record exactly where the base scalers are 1 (x * (1/1), x * 1) */
+                const float a0[2] = { a.scl[a.map[0]], a.scl[a.map[1]] }, a1[2] = { b.scl[b.map[0]], b.scl[b.map[1]] };
+                bool textured = false;                      /* a one-texel texture is read at (0, 0) whatever the scale */
+                for (int side = 0; side < 2; side++)
+                {
+                    const int32_t mi = v.srf[next[i].srf].mat[side];
+                    if (mi != QR_NULL && (v.mat[mi].xmask != 0 || v.mat[mi].ymask != 0)) textured = true;
+                }
+                if (textured && !same_bits(a0, a1, sizeof(a0)))
+                {
+                    if (a0[0] != 1.0f || a0[1] != 1.0f)
+                        return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": a scaled plane's axis scalers change (its materials' texture scale is not recoverable from the snapshot)");
+                    plane_tex.push_back(i);
+                }
+            }
         }
         for (int i = n - 1; i >= 0; i--)
         {
@@ -369,6 +395,14 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         }
     }
 
+    for (int i : self_of)
+    {
+        const int32_t srf = next[i].srf;
+        bool clips = v.srf[srf].clip != QR_NULL;
+        for (uint32_t q = 0; q < v.hdr->n_srf && !clips; q++)
+            for (int32_t e = v.srf[q].clip; e != QR_NULL && !clips; e = v.elm[e].next) clips = v.elm[e].simd == srf;
+        if (clips) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": becomes (or stops being) a transform node while it takes part in custom clipping");
+    }
     /* ---- transform nodes that appear or vanish: records, and the elements of the global list ---- */
     std::vector<qr_node> nodes_w;                           /* `next` with the records of new transform nodes entered */
     std::vector<qr_surface> S_w;
@@ -537,6 +571,35 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         {
             /* rt_Light::update_fields 649-667 */
             L[nd.lgt].pos[0] = m[3][0]; L[nd.lgt].pos[1] = m[3][1]; L[nd.lgt].pos[2] = m[3][2];
+        }
+    }
+    for (int i : self_of)
+        if (st[(size_t)i].trnode < 0)
+        {
+            /* no transform node any more: the engine's record of such a surface holds no matrix (the field is never read) */
+            qr_surface &r = S[next[i].srf];
+            for (int c = 0; c < 3; c++) r.tci[c] = r.tcj[c] = r.tck[c] = 0.0f;
+        }
+    if (!plane_tex.empty())
+    {
+        qr_material *M = (qr_material *)(out.data() + hdr_w.off_mat);
+        for (int i : plane_tex)
+        {
+            const qr_node_state &b = st[(size_t)i];
+            const float asc[2] = { b.scl[b.map[0]], b.scl[b.map[1]] };
+            const float isc[2] = { 1.0f / asc[0], 1.0f / asc[1] };
+            const int32_t *mats = v.srf[next[i].srf].mat;
+            for (int side = 0; side < 2; side++)
+            {
+                const int32_t mi = mats[side];
+                if (mi == QR_NULL || (side == 1 && mi == mats[0])) continue;
+                const qr_material &m0 = v.mat[mi];
+                if ((uint32_t)m0.t_map[0] > 1u || (uint32_t)m0.t_map[1] > 1u) return qr_fail(QR_ERR_ARG, "material: texture axis out of range");
+                M[mi].xscal = m0.xscal * isc[m0.t_map[0]];
+                M[mi].yscal = m0.yscal * isc[m0.t_map[1]];
+                M[mi].xoffs = m0.xoffs * asc[m0.t_map[0]];
+                M[mi].yoffs = m0.yoffs * asc[m0.t_map[1]];
+            }
         }
     }
     if (flags & QR_HIER_BOUNDS)
