@@ -22,16 +22,27 @@
  * of transform nodes ("trnodes": nodes with a non-trivial rotation) and every node's axis mapping and scalers stay
  * the same, and no array with a bounding volume moves -- unless the node tables carry the bounds inputs and
  * QR_HIER_BOUNDS is given: then clip boxes and bounding volumes are recomputed like the engine does (rt_Surface::
- * update_minmax, rt_Array::update_bounds).  A changing SET of transform nodes (round 4): an ARRAY may start or stop being
- * the transform node of surfaces that hang directly in the global list and take no part in custom clipping -- the rotating
- * light arrays of the demo scenes; qr_hierarchy_apply then creates (drops) the node's record and its element of the global
- * list, needs both node tables (`base`) and QR_HIER_RESET_TILES, and returns a LARGER snapshot.  Members inside another
- * array's run of the list, or clippers, would need the engine's ordered insert (engine.cpp:1116-1645, rtgeom.cpp:1244) and
- * are refused with QR_ERR_UNSUP naming the node.  A SURFACE may start or stop being its OWN transform node (a right angle
- * <-> any angle): its record takes / loses the matrix, no list element changes; refused while it takes part in custom
- * clipping.  When a textured plane's axis scalers change with that (the scale moves into or out of the matrix), the texture
- * scale and offset of its two materials follow (rt_Plane::update_fields, object.cpp:2893-2938) -- provided the base scalers
- * are 1, where the material's own scale can be read back from its record exactly; otherwise QR_ERR_UNSUP.
+ * update_minmax, rt_Array::update_bounds).
+ *
+ * A changing SET of transform nodes (round 4) -- any object may start or stop turning.  Needs both node tables (`base`),
+ * QR_HIER_BOUNDS and QR_HIER_RESET_TILES, and returns a LARGER snapshot:
+ *   - the global list holds one element per ARRAY that is the transform node of surfaces, in front of its members, which stand
+ *     together (rt_SceneThread::insert, engine.cpp:1148-1214).  When surfaces change that array -- an array under a turning
+ *     array starts to turn itself, an array returns to a right angle, the rotating light arrays of the demo scenes -- the list
+ *     is regrouped: every group where its first member stood, members in list order, other surfaces where they were;
+ *   - every clipper list is regrouped the same way between its accum markers (engine.cpp:1845-1947: transform-node markers in
+ *     front of the clippers that share an array);
+ *   - an array that becomes a transform node and has no record gets one: the k-th such array in NODE ORDER holds record
+ *     n_srf + k of the returned snapshot (enter it into the table before patching that snapshot again);
+ *   - a SURFACE that starts or stops being its OWN transform node (a right angle <-> any angle) changes no list: its record
+ *     takes / loses the matrix;
+ *   - a textured plane's axis scalers enter the texture scale and offset of its two materials (rt_Plane::update_fields,
+ *     object.cpp:2893-2938): they follow, from qr_node.tex when the table carries it, else read back from the record where
+ *     the base scalers are 1 (exact there); otherwise QR_ERR_UNSUP naming the node.
+ * The ORDER of the regrouped lists is the previous order, not the view order the engine's insert (engine.cpp:1216-1645 over
+ * bbox_sort, rtgeom.cpp:1244) would give them this frame: order decides nothing but exact depth ties.  The engine's removal
+ * of fully hidden surfaces from its camera list (RT_OPTS_REMOVE) is undone, not redone: with `base` and QR_HIER_RESET_TILES a
+ * list that lacks surfaces of the table gets them back behind the others.
  *
  * Plain C ABI; fp32 arithmetic in the reference's operation order: the results are bit-identical to the engine's
  * (tests/test_hierarchy.py, fixtures dumped from the engine by oracle/ref_driver.cpp --tree).
@@ -79,6 +90,12 @@ typedef struct qr_node
                              * 3190-3196, ...), 0 when it does not                                                   */
     float   lmin[3], lmax[3];   /* surfaces: the axis clippers of the scene description (rt_SURFACE::min / max, local axes
                                  * I, J, K; -/+FLT_MAX = none, as RT_INF)                                            */
+    /* planes: texture scale (x, y) and position (x, y) of the outer, then of the inner material before the plane's axis
+     * scalers enter them (rt_Material::scl, rt_SIDE::pos; rt_Plane::update_fields, object.cpp:2893-2938 multiplies the
+     * scalers in).  has_tex 0: not given -- then a textured plane's scalers may only change away from 1 */
+    float   tex[8];
+    int32_t has_tex;
+    int32_t pad_[3];
 } qr_node;
 
 /* What the bounds update computes per node (members of rt_BOUND / rt_SHAPE and of rt_Array's three boxes). */

@@ -299,6 +299,14 @@ static void dump_node(FILE *f, rt_Object *o, int parent, std::vector<rt_Object *
         fprintf(f, ", "); put_f(f, "cmin", sf->shape->cmin, 3); fprintf(f, ", "); put_f(f, "cmax", sf->shape->cmax, 3);
         fprintf(f, ", "); put_f(f, "mid", sf->bvbox->mid, 3); fprintf(f, ", "); put_f(f, "rad", &sf->bvbox->rad, 1);
         fprintf(f, ", \"verts_num\": %d", (int)sf->bvbox->verts_num);
+        if (o->tag == RT_TAG_PLANE)
+        {
+            /* texture scale and position of the two materials before the plane's axis scalers enter them
+             * (rt_Plane::update_fields, object.cpp:2893-2938): outer scl x, y, pos x, y, then inner */
+            const rt_real tex[8] = { sf->outer->scl[0], sf->outer->scl[1], sf->outer->sd->pos[0], sf->outer->sd->pos[1],
+                                     sf->inner->scl[0], sf->inner->scl[1], sf->inner->sd->pos[0], sf->inner->sd->pos[1] };
+            fprintf(f, ", "); put_f(f, "tex", tex, 8);
+        }
     }
     if (o->tag == RT_TAG_ARRAY)
     {

@@ -159,7 +159,8 @@ def node_dtype():
     import numpy as np
     return np.dtype([("parent", "<i4"), ("tag", "<i4"), ("scl", "<f4", 3), ("rot", "<f4", 3), ("pos", "<f4", 3),
                      ("shape", "<f4", 3), ("srf", "<i4"), ("inb", "<i4"), ("bvb", "<i4"), ("lgt", "<i4"), ("anim", "<i4"),
-                     ("pov", "<f4"), ("bvnode", "<i4"), ("nverts", "<i4"), ("lmin", "<f4", 3), ("lmax", "<f4", 3)])
+                     ("pov", "<f4"), ("bvnode", "<i4"), ("nverts", "<i4"), ("lmin", "<f4", 3), ("lmax", "<f4", 3),
+                     ("tex", "<f4", 8), ("has_tex", "<i4"), ("pad_", "<i4", 3)])
 
 
 def node_bounds_dtype():
@@ -244,6 +245,27 @@ def hierarchy_apply(blob, nodes, opts, camera=-1, base=None, flags=0):
         return ctypes.string_at(out, n.value)
     finally:
         lib().qr_free(out)
+
+
+def hierarchy_records_after_apply(blob, nodes, opts):
+    """The node table as it stands after hierarchy_apply(blob, nodes, ...): an array that became the transform node of surfaces
+    and had no record got one -- the k-th such array in node order holds record n_srf + k (include/qr_hierarchy.h).  Use it
+    as `base` (and for `srf` of the next table) when the patched snapshot is patched again."""
+    import struct
+    import numpy as np
+    nodes = np.ascontiguousarray(nodes, dtype=node_dtype()).copy()
+    st = hierarchy_update(nodes, opts)
+    n_srf = struct.unpack_from("<I", blob, 16)[0]
+    heads = set()
+    for i in range(len(nodes)):
+        t = int(st[i]["trnode"])
+        if 0 <= nodes[i]["tag"] < 9 and nodes[i]["srf"] >= 0 and t >= 0 and t != i:
+            heads.add(t)
+    for g in sorted(heads):
+        if nodes[g]["srf"] < 0:
+            nodes[g]["srf"] = n_srf
+            n_srf += 1
+    return nodes
 
 
 def program_stats(blob):

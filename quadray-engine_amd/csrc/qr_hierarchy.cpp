@@ -309,8 +309,8 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     int rc = qr_snapshot_validate(v, err);
     if (rc != QR_OK) return qr_fail(rc, err);
     std::vector<qr_node_state> st((size_t)(n > 0 ? n : 0)), st0;
-    std::vector<std::pair<int, int>> born_of, died_of;      /* (array node, member surface node): transform nodes that appear / vanish */
-    std::vector<int> self_of;                               /* surfaces that become / stop being their own transform node */
+    bool regroup = false;                                   /* surfaces change the array that is their transform node */
+    std::vector<int> self_of;                               /* surfaces whose transform node changes (another array, themselves, none) */
     std::vector<int> plane_tex;                             /* planes whose axis scalers leave 1: texture scale / offset of their materials */
     rc = run_update(next, n, opts, st.data(), err);
     if (rc != QR_OK) return qr_fail(rc, err);
@@ -322,7 +322,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         for (int r : refs) if (r < -1 || r >= n_srf) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": surface record out of range");
         if (nd.tag == QR_NODE_LIGHT && (nd.lgt < -1 || nd.lgt >= n_lgt)) return qr_fail(QR_ERR_ARG, "node " + std::to_string(i) + ": light record out of range");
         if (st[(size_t)i].trnode >= 0 && st[(size_t)i].trnode != i && (is_surface(nd.tag) || nd.tag == QR_NODE_ARRAY) && nd.srf >= 0
-            && next[st[(size_t)i].trnode].srf < 0 && (base == nullptr || !is_surface(nd.tag)))
+            && next[st[(size_t)i].trnode].srf < 0 && base == nullptr)
             return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": its transform node has no record in the snapshot");
     }
     if (camera >= n || (camera >= 0 && next[camera].tag != QR_NODE_CAMERA)) return qr_fail(QR_ERR_ARG, "camera is not a camera node");
@@ -343,25 +343,22 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
             const bool has_record = (is_surface(next[i].tag) || next[i].tag == QR_NODE_ARRAY) && next[i].srf >= 0;
             if (has_record && (a.trnode != b.trnode || a.obj_has_trm != b.obj_has_trm))
             {
-                /* The set of transform nodes changes.  Supported (round 4): an ARRAY starts or stops being the transform node
-                 * of surfaces that hang directly in the global list -- the rotating light arrays of the demo scenes, whose
-                 * bulb becomes the member of a transform node the moment the array leaves a right angle (scn_demo01.h:513-561).
-                 * The record and the list element of such a node are created / removed below; everything else still needs the
-                 * engine's snode / insert (engine.cpp:1116-1814) and is refused. */
-                const int t_new = b.trnode, t_old = a.trnode;
-                const bool born = is_surface(next[i].tag) && t_old < 0 && t_new >= 0 && t_new != i && next[t_new].tag == QR_NODE_ARRAY
-                               && st0[(size_t)t_new].trnode < 0;
-                const bool died = is_surface(next[i].tag) && t_new < 0 && t_old >= 0 && t_old != i && next[t_old].tag == QR_NODE_ARRAY
-                               && next[t_old].srf >= 0 && st[(size_t)t_old].trnode < 0;
-                if (born) born_of.push_back(std::make_pair(t_new, i));
-                else if (died) died_of.push_back(std::make_pair(t_old, i));
-                /* a surface that becomes (or stops being) its OWN transform node: its record carries the matrix itself and the
-                 * lists hold no element for it -- only custom clipping would (its clippers' lists carry transform-node markers) */
-                const bool self = !born && !died && is_surface(next[i].tag) && ((t_old < 0 && t_new == i) || (t_new < 0 && t_old == i));
-                if (self) self_of.push_back(i);
-                const bool stops = next[i].tag == QR_NODE_ARRAY && next[i].srf >= 0 && b.trnode != i && a.trnode == i;   /* the array that stops: handled through its members */
-                if (!born && !died && !self && !stops)
-                    return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": the set of transform nodes changes (list structure would)");
+                /* The set of transform nodes changes.  The global list holds one element per ARRAY that is the transform node of
+                 * surfaces, in front of its members, which stand together (rt_SceneThread::insert, engine.cpp:1148-1214; bounding-
+                 * volume arrays are not in a camera list when the screen is tiled, 1711-1725): when surfaces change their array
+                 * -- the rotating light arrays of the demo scenes (scn_demo01.h:513-561), an array under a turning array that
+                 * starts to turn itself, any of them stopping -- the list is regrouped below and records of new transform nodes
+                 * are created.  A surface that becomes (or stops being) its OWN transform node changes no element: its record
+                 * carries the matrix itself.  Custom clipping is where it ends: clippers' lists carry transform-node markers of
+                 * their own (engine.cpp:1845-1947) */
+                if (is_surface(next[i].tag))
+                {
+                    const int g_old = a.trnode >= 0 && a.trnode != i ? a.trnode : -1, g_new = b.trnode >= 0 && b.trnode != i ? b.trnode : -1;
+                    if (g_old != g_new) regroup = true;
+                    if (g_old != g_new || (a.trnode == i) != (b.trnode == i)) self_of.push_back(i);
+                    if (g_new >= 0 && next[g_new].tag != QR_NODE_ARRAY)
+                        return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": its transform node is not an array");
+                }
             }
             if (has_record && !(flags & QR_HIER_BOUNDS) &&
                 (!same_bits(a.map, b.map, sizeof(a.map)) || !same_bits(a.sgn, b.sgn, sizeof(a.sgn)) || !same_bits(a.scl, b.scl, sizeof(a.scl))))
@@ -381,8 +378,8 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                 }
                 if (textured && !same_bits(a0, a1, sizeof(a0)))
                 {
-                    if (a0[0] != 1.0f || a0[1] != 1.0f)
-                        return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": a scaled plane's axis scalers change (its materials' texture scale is not recoverable from the snapshot)");
+                    if (!next[i].has_tex && (a0[0] != 1.0f || a0[1] != 1.0f))
+                        return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": a scaled plane's axis scalers change (its materials' texture scale is not recoverable from the snapshot: give qr_node.tex)");
                     plane_tex.push_back(i);
                 }
             }
@@ -395,20 +392,22 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         }
     }
 
-    for (int i : self_of)
-    {
-        const int32_t srf = next[i].srf;
-        bool clips = v.srf[srf].clip != QR_NULL;
-        for (uint32_t q = 0; q < v.hdr->n_srf && !clips; q++)
-            for (int32_t e = v.srf[q].clip; e != QR_NULL && !clips; e = v.elm[e].next) clips = v.elm[e].simd == srf;
-        if (clips) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(i) + ": becomes (or stops being) a transform node while it takes part in custom clipping");
-    }
-    /* ---- transform nodes that appear or vanish: records, and the elements of the global list ---- */
+    /* ---- surfaces change their array: records of new transform nodes, and the global list regrouped ---- */
     std::vector<qr_node> nodes_w;                           /* `next` with the records of new transform nodes entered */
     std::vector<qr_surface> S_w;
     std::vector<qr_elem> E_w;
     int32_t clist_w = v.frame->clist;
-    const bool restructure = !born_of.empty() || !died_of.empty();
+    /* the engine removes surfaces that are fully hidden behind others from its camera list (RT_OPTS_REMOVE, the 4|x results of
+     * bbox_sort, rtgeom.cpp:1551-1560): a list that lacks surfaces of the table is only good for the frame it was made for */
+    bool incomplete = false;
+    if (base != nullptr && (flags & QR_HIER_RESET_TILES))
+    {
+        size_t in_list = 0, in_table = 0;
+        for (int32_t e = clist_w; e != QR_NULL; e = v.elm[e].next) if (v.elm[e].data == QR_NULL) in_list++;
+        for (int i = 0; i < n; i++) if (is_surface(next[i].tag) && next[i].srf >= 0) in_table++;
+        incomplete = in_list < in_table;
+    }
+    const bool restructure = regroup || incomplete;
     if (restructure)
     {
         if (!(flags & QR_HIER_RESET_TILES))
@@ -416,100 +415,133 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         nodes_w.assign(next, next + n);
         S_w.assign(v.srf, v.srf + v.hdr->n_srf);
         E_w.assign(v.elm, v.elm + v.hdr->n_elm);
-        /* a member must hang in the global list itself (not inside another array's run), own no clipper list and clip nobody:
-         * clipper lists carry transform-node markers of their own (engine.cpp:1845-1947) */
-        auto top_level_elem = [&](int32_t srf, int32_t &prev_out) -> int32_t {
-            int32_t prev = QR_NULL;
-            for (int32_t e = clist_w; e != QR_NULL; )
-            {
-                const qr_elem &el = E_w[(size_t)e];
-                if (el.simd == srf && el.data == QR_NULL) { prev_out = prev; return e; }
-                if (el.data != QR_NULL)
-                {
-                    /* an array element: its run [next .. data] is not top level -- skip behind it */
-                    for (int32_t m = el.next; m != QR_NULL; m = E_w[(size_t)m].next)
-                    {
-                        if (E_w[(size_t)m].simd == srf) return QR_NULL - 1;
-                        if (m == el.data) break;
-                    }
-                    prev = el.data; e = E_w[(size_t)el.data].next;
-                    continue;
-                }
-                prev = e; e = el.next;
-            }
-            return QR_NULL - 1;
-        };
-        auto clips_or_is_clipped = [&](int32_t srf) {
-            if (S_w[(size_t)srf].clip != QR_NULL) return true;
-            for (size_t q = 0; q < S_w.size(); q++)
-                for (int32_t e = S_w[q].clip; e != QR_NULL; e = E_w[(size_t)e].next)
-                    if (E_w[(size_t)e].simd == srf) return true;
-            return false;
-        };
-        /* vanished transform nodes: the array's element leaves the list, its members stay where they are */
-        std::sort(died_of.begin(), died_of.end());
-        for (size_t q = 0; q < died_of.size(); q++)
+        std::vector<int> node_of_rec((size_t)n_srf, -1), head_of_rec((size_t)n_srf, -1);
+        for (int i = 0; i < n; i++)
         {
-            if (q > 0 && died_of[q].first == died_of[q - 1].first) continue;
-            const int32_t rec = next[died_of[q].first].srf;
-            int32_t prev = QR_NULL, te = QR_NULL;
-            for (int32_t e = clist_w; e != QR_NULL; prev = e, e = E_w[(size_t)e].next)
-                if (E_w[(size_t)e].simd == rec && E_w[(size_t)e].data != QR_NULL) { te = e; break; }
-            if (te == QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": its transform-node element is not in the global list's top level");
-            for (int32_t m = E_w[(size_t)te].next; ; m = E_w[(size_t)m].next)
-            {
-                if (m == QR_NULL || E_w[(size_t)m].data != QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": nested arrays under a vanishing transform node");
-                if (clips_or_is_clipped(E_w[(size_t)m].simd)) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(died_of[q].first) + ": a member takes part in custom clipping");
-                if (m == E_w[(size_t)te].data) break;
-            }
-            if (prev == QR_NULL) clist_w = E_w[(size_t)te].next; else E_w[(size_t)prev].next = E_w[(size_t)te].next;
+            if (is_surface(next[i].tag) && next[i].srf >= 0) node_of_rec[(size_t)next[i].srf] = i;
+            if (next[i].tag == QR_NODE_ARRAY && next[i].srf >= 0) head_of_rec[(size_t)next[i].srf] = i;
         }
-        /* new transform nodes: a record (rt_Array's s_srf as rt_Node::update_fields fills it, object.cpp:813-843: tag -1, no
-         * solver, its own transform node) and an element in front of the members, which move together behind it */
-        std::sort(born_of.begin(), born_of.end());
-        for (size_t q = 0; q < born_of.size(); )
+        /* the leaves of the list in its order; array elements must be what the base state says they are */
+        std::vector<int> leaf;                              /* node of every leaf, in list order */
+        for (int32_t e = clist_w; e != QR_NULL; e = v.elm[e].next)
         {
-            const int arr = born_of[q].first;
-            size_t q1 = q;
-            while (q1 < born_of.size() && born_of[q1].first == arr) q1++;
+            const qr_elem &el = v.elm[e];
+            if (el.data != QR_NULL)
+            {
+                const int arr = head_of_rec[(size_t)el.simd];
+                if (arr < 0 || el.kind != 0 || st0[(size_t)arr].trnode != arr)
+                    return qr_fail(QR_ERR_UNSUP, "the global list holds an array element that is not a transform node of the base table: cannot regroup it");
+                continue;
+            }
+            const int nd = node_of_rec[(size_t)el.simd];
+            if (nd < 0) return qr_fail(QR_ERR_UNSUP, "the global list holds a surface no node of the table owns: cannot regroup it");
+            leaf.push_back(nd);
+        }
+        if (incomplete)
+        {
+            /* surfaces the engine had removed come back behind the others */
+            std::vector<char> listed((size_t)n, 0);
+            for (int nd : leaf) listed[(size_t)nd] = 1;
+            for (int i = 0; i < n; i++)
+                if (is_surface(next[i].tag) && next[i].srf >= 0 && !listed[(size_t)i]) leaf.push_back(i);
+        }
+        auto group_of = [&](int nd) { const int t = st[(size_t)nd].trnode; return t >= 0 && t != nd ? t : -1; };
+        /* records of arrays that become transform nodes (rt_Array's s_srf as rt_Node::update_fields fills it, object.cpp:813-843:
+         * tag -1, no solver, its own transform node); an array that was one before still has its record */
+        std::vector<char> heads_surfaces((size_t)n, 0);
+        for (int nd = 0; nd < n; nd++)
+            if (is_surface(next[nd].tag) && next[nd].srf >= 0 && group_of(nd) >= 0) heads_surfaces[(size_t)group_of(nd)] = 1;
+        for (int g = 0; g < n; g++)                         /* in node order: the k-th new record is n_srf + k (qr_hierarchy.h) */
+        {
+            if (!heads_surfaces[(size_t)g] || nodes_w[(size_t)g].srf >= 0) continue;
             qr_surface rec; memset(&rec, 0, sizeof(rec));
-            rec.c_def = 0xFFFFFFFFu; rec.smask = 0x80000000u; rec.d_eps = 1e-11f; rec.t_eps = 1e-7f;       /* RT_CULL_THRESHOLD / RT_CLIP_THRESHOLD-independent constants of every record: object.h:41-42 */
+            rec.c_def = 0xFFFFFFFFu; rec.smask = 0x80000000u; rec.d_eps = 1e-11f; rec.t_eps = 1e-7f;       /* the constants of every record: object.h:41-42 */
             rec.srf_t[3] = QR_NODE_ARRAY; rec.clip = QR_NULL; rec.trnode = (int32_t)S_w.size();
             rec.mat[0] = rec.mat[1] = QR_NULL; for (int k = 0; k < 4; k++) rec.lst[k] = QR_NULL;
-            const int32_t rec_ix = (int32_t)S_w.size();
+            nodes_w[(size_t)g].srf = (int32_t)S_w.size();
             S_w.push_back(rec);
-            nodes_w[(size_t)arr].srf = rec_ix;
-            /* unlink the members (list order kept), then link [array element, members...] where the first one stood */
-            std::vector<int32_t> mem;
-            int32_t anchor_prev = QR_NULL; bool have_anchor = false;
-            std::vector<std::pair<int32_t, int32_t>> found;         /* (position in the list, element) */
-            for (size_t k = q; k < q1; k++)
+        }
+        /* the new list, in fresh elements (the old chain may share cells with other lists): every group where its first member
+         * stood -- [array element, members in list order], `data` of the array element = the last member -- other leaves alone */
+        std::vector<char> placed(leaf.size(), 0);
+        int32_t tail = QR_NULL; clist_w = QR_NULL;
+        auto append = [&](int32_t simd) -> int32_t {
+            qr_elem ne; ne.simd = simd; ne.data = QR_NULL; ne.next = QR_NULL; ne.kind = 0;
+            const int32_t ix = (int32_t)E_w.size();
+            E_w.push_back(ne);
+            if (tail == QR_NULL) clist_w = ix; else E_w[(size_t)tail].next = ix;
+            tail = ix;
+            return ix;
+        };
+        for (size_t k = 0; k < leaf.size(); k++)
+        {
+            if (placed[k]) continue;
+            const int g = group_of(leaf[k]);
+            if (g < 0) { append(next[leaf[k]].srf); placed[k] = 1; continue; }
+            const int32_t head = append(nodes_w[(size_t)g].srf);
+            for (size_t m = k; m < leaf.size(); m++)
+                if (!placed[m] && group_of(leaf[m]) == g) { E_w[(size_t)head].data = append(next[leaf[m]].srf); placed[m] = 1; }
+        }
+        /* clipper lists (engine.cpp:1845-1947): accum markers (no record; data -1 / +1), clippers (data = the side that clips) and
+         * transform-node markers (kind 2, data = the last clipper under them) in front of the clippers that share an array -- the
+         * same regrouping, stretch by stretch between the accum markers.  The order of clippers inside a stretch is free (every
+         * one of them must pass / any of an accum segment); lists none of whose clippers changes its array stay as they are */
+        auto group_before = [&](int nd) { const int t = st0[(size_t)nd].trnode; return t >= 0 && t != nd ? t : -1; };
+        std::vector<std::pair<int32_t, int32_t>> redone;    /* (old head, new head): lists are shared between records */
+        for (size_t q = 0; q < (size_t)n_srf; q++)
+        {
+            const int32_t h = v.srf[q].clip;
+            if (h == QR_NULL) continue;
+            size_t k = 0;
+            while (k < redone.size() && redone[k].first != h) k++;
+            if (k < redone.size()) { S_w[q].clip = redone[k].second; continue; }
+            bool changes = false;
+            for (int32_t e = h; e != QR_NULL; e = v.elm[e].next)
             {
-                const int32_t srf = next[born_of[k].second].srf;
-                if (clips_or_is_clipped(srf)) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(born_of[k].second) + ": takes part in custom clipping under a new transform node");
-                int32_t pv = QR_NULL;
-                const int32_t e = top_level_elem(srf, pv);
-                if (e < QR_NULL) return qr_fail(QR_ERR_UNSUP, "node " + std::to_string(born_of[k].second) + ": not in the global list's top level (nested arrays need the engine's insert)");
-                int32_t posn = 0; for (int32_t w = clist_w; w != e; w = E_w[(size_t)w].next) posn++;
-                found.push_back(std::make_pair(posn, e));
+                const qr_elem &el = v.elm[e];
+                if (el.kind == 2 || el.simd == QR_NULL) continue;
+                const int nd = node_of_rec[(size_t)el.simd];
+                if (nd < 0) return qr_fail(QR_ERR_UNSUP, "a clipper list holds a surface no node of the table owns: cannot regroup it");
+                if (group_before(nd) != group_of(nd)) changes = true;
             }
-            std::sort(found.begin(), found.end());
-            for (size_t k = 0; k < found.size(); k++)
+            int32_t nh = h;
+            if (changes)
             {
-                int32_t pv = QR_NULL;
-                for (int32_t w = clist_w; w != found[k].second; w = E_w[(size_t)w].next) pv = w;
-                if (!have_anchor) { anchor_prev = pv; have_anchor = true; }
-                if (pv == QR_NULL) clist_w = E_w[(size_t)found[k].second].next; else E_w[(size_t)pv].next = E_w[(size_t)found[k].second].next;
-                mem.push_back(found[k].second);
+                int32_t ltail = QR_NULL; nh = QR_NULL;
+                auto put = [&](const qr_elem &src) -> int32_t {
+                    qr_elem ne = src; ne.next = QR_NULL;
+                    const int32_t ix = (int32_t)E_w.size();
+                    E_w.push_back(ne);
+                    if (ltail == QR_NULL) nh = ix; else E_w[(size_t)ltail].next = ix;
+                    ltail = ix;
+                    return ix;
+                };
+                std::vector<int32_t> run;                   /* clippers of the stretch being collected */
+                auto flush = [&]() {
+                    std::vector<char> done(run.size(), 0);
+                    for (size_t a = 0; a < run.size(); a++)
+                    {
+                        if (done[a]) continue;
+                        const int g = group_of(node_of_rec[(size_t)v.elm[run[a]].simd]);
+                        if (g < 0) { put(v.elm[run[a]]); done[a] = 1; continue; }
+                        qr_elem mk; mk.simd = nodes_w[(size_t)g].srf; mk.data = QR_NULL; mk.next = QR_NULL; mk.kind = 2;
+                        const int32_t head = put(mk);
+                        for (size_t b = a; b < run.size(); b++)
+                            if (!done[b] && group_of(node_of_rec[(size_t)v.elm[run[b]].simd]) == g) { E_w[(size_t)head].data = put(v.elm[run[b]]); done[b] = 1; }
+                    }
+                    run.clear();
+                };
+                for (int32_t e = h; e != QR_NULL; e = v.elm[e].next)
+                {
+                    const qr_elem &el = v.elm[e];
+                    if (el.kind == 2) continue;
+                    if (el.simd == QR_NULL) { flush(); put(el); }
+                    else run.push_back(e);
+                }
+                flush();
             }
-            qr_elem te; te.simd = rec_ix; te.kind = 0; te.data = mem.back(); te.next = mem.front();
-            const int32_t te_ix = (int32_t)E_w.size();
-            E_w.push_back(te);
-            const int32_t after = anchor_prev == QR_NULL ? clist_w : E_w[(size_t)anchor_prev].next;
-            for (size_t k = 0; k + 1 < mem.size(); k++) E_w[(size_t)mem[k]].next = mem[k + 1];
-            E_w[(size_t)mem.back()].next = after;
-            if (anchor_prev == QR_NULL) clist_w = te_ix; else E_w[(size_t)anchor_prev].next = te_ix;
-            q = q1;
+            redone.push_back(std::make_pair(h, nh));
+            S_w[q].clip = nh;
         }
         next = nodes_w.data();
     }
@@ -574,9 +606,9 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         }
     }
     for (int i : self_of)
-        if (st[(size_t)i].trnode < 0)
+        if (st[(size_t)i].trnode != i && st0[(size_t)i].trnode == i)
         {
-            /* no transform node any more: the engine's record of such a surface holds no matrix (the field is never read) */
+            /* not its own transform node any more: the engine's record of such a surface holds no matrix (the field is never read) */
             qr_surface &r = S[next[i].srf];
             for (int c = 0; c < 3; c++) r.tci[c] = r.tcj[c] = r.tck[c] = 0.0f;
         }
@@ -595,10 +627,14 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                 if (mi == QR_NULL || (side == 1 && mi == mats[0])) continue;
                 const qr_material &m0 = v.mat[mi];
                 if ((uint32_t)m0.t_map[0] > 1u || (uint32_t)m0.t_map[1] > 1u) return qr_fail(QR_ERR_ARG, "material: texture axis out of range");
-                M[mi].xscal = m0.xscal * isc[m0.t_map[0]];
-                M[mi].yscal = m0.yscal * isc[m0.t_map[1]];
-                M[mi].xoffs = m0.xoffs * asc[m0.t_map[0]];
-                M[mi].yoffs = m0.yoffs * asc[m0.t_map[1]];
+                /* the material's own scale and position: given in the node table, or read back from the record (base scalers 1) */
+                const float *tx = next[i].tex + 4 * side;
+                const float sx = next[i].has_tex ? tx[0] : m0.xscal, sy = next[i].has_tex ? tx[1] : m0.yscal;
+                const float px = next[i].has_tex ? tx[2 + m0.t_map[0]] : m0.xoffs, py = next[i].has_tex ? tx[2 + m0.t_map[1]] : m0.yoffs;
+                M[mi].xscal = sx * isc[m0.t_map[0]];
+                M[mi].yscal = sy * isc[m0.t_map[1]];
+                M[mi].xoffs = px * asc[m0.t_map[0]];
+                M[mi].yoffs = py * asc[m0.t_map[1]];
             }
         }
     }

@@ -30,6 +30,14 @@ EXTRA = {
 }
 
 
+# Every transform of a scene drawn anew (--jitter SEED) with the engine's screen tiling off (its tiling is not conservative on
+# such transforms, tests/test_rebin_pin.py): tree + the reference's frame.  Tests patch the t = 0 snapshot of the scene (default
+# options) with this tree -- surfaces change the array that is their transform node, become their own, stop; nested arrays,
+# bounding volumes and custom clipping included -- and must get this frame.
+JITTER = [("demo01", 1), ("demo02", 3), ("demo03", 3), ("test02", 23), ("test03", 22), ("test11", 23), ("test12", 21),
+          ("test13", 1), ("test14", 1), ("test16", 3)]
+
+
 # fuzzed transforms (oracle/ref_driver.cpp --jitter SEED: right-angle and arbitrary rotations, negative and non-unit scalers,
 # shifted positions on every object of the scene's static description): tree + the snapshot of that run with its texels
 # zeroed (the hierarchy tests do not look at them; 160 KB of texture would travel with every case otherwise)
@@ -75,6 +83,19 @@ def main():
     for name, (scene, args) in sorted(EXTRA.items()):
         tmp = tempfile.mkdtemp(prefix="qrtree_")
         frame, _, tree = run(scene, 160, 120, args, tmp)
+        with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
+            f.write(gzip.compress(tree, 9, mtime=0))
+        bio = io.BytesIO(); np.save(bio, frame.astype("<u4"))
+        with open(os.path.join(OUT, name + ".frame.npy.gz"), "wb") as f:
+            f.write(gzip.compress(bio.getvalue(), 9, mtime=0))
+        print(name, "frame + tree")
+
+
+def jitter():
+    for scene, seed in JITTER:
+        tmp = tempfile.mkdtemp(prefix="qrtree_")
+        frame, _, tree = run(scene, 160, 120, ["--jitter", str(seed), "--opts-off", "tiling"], tmp)
+        name = "%s_160_jt%d" % (scene, seed)
         with open(os.path.join(OUT, name + ".json.gz"), "wb") as f:
             f.write(gzip.compress(tree, 9, mtime=0))
         bio = io.BytesIO(); np.save(bio, frame.astype("<u4"))
@@ -129,7 +150,10 @@ if __name__ == "__main__":
         fuzz()
     elif sys.argv[1:] == ["moved"]:
         moved()
+    elif sys.argv[1:] == ["jitter"]:
+        jitter()
     else:
         main()
+        jitter()
         fuzz()
         moved()
