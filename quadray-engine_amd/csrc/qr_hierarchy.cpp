@@ -412,6 +412,8 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
     {
         if (!(flags & QR_HIER_RESET_TILES))
             return qr_fail(QR_ERR_ARG, "the set of transform nodes changes: the tile lists go stale, pass QR_HIER_RESET_TILES (and rebuild the lists)");
+        if (regroup && !(flags & QR_HIER_BOUNDS))
+            return qr_fail(QR_ERR_ARG, "the set of transform nodes changes: the members' boxes move to another space, pass QR_HIER_BOUNDS (node tables with the bounds inputs)");
         nodes_w.assign(next, next + n);
         S_w.assign(v.srf, v.srf + v.hdr->n_srf);
         E_w.assign(v.elm, v.elm + v.hdr->n_elm);
@@ -499,7 +501,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
             for (int32_t e = h; e != QR_NULL; e = v.elm[e].next)
             {
                 const qr_elem &el = v.elm[e];
-                if (el.kind == 2 || el.simd == QR_NULL) continue;
+                if (el.simd == QR_NULL || el.kind == 2 || v.srf[el.simd].srf_t[3] < 0) continue;
                 const int nd = node_of_rec[(size_t)el.simd];
                 if (nd < 0) return qr_fail(QR_ERR_UNSUP, "a clipper list holds a surface no node of the table owns: cannot regroup it");
                 if (group_before(nd) != group_of(nd)) changes = true;
@@ -534,7 +536,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                 for (int32_t e = h; e != QR_NULL; e = v.elm[e].next)
                 {
                     const qr_elem &el = v.elm[e];
-                    if (el.kind == 2) continue;
+                    if (el.simd != QR_NULL && (el.kind == 2 || v.srf[el.simd].srf_t[3] < 0)) continue;
                     if (el.simd == QR_NULL) { flush(); put(el); }
                     else run.push_back(e);
                 }
