@@ -289,6 +289,56 @@ def test_gpu_animated_snapshot_gives_the_reference_frame_of_that_time(qr, base_n
     assert (frame == _target_frame(target_name, where)).all()
 
 
+def _shuffled_global_list(blob, seed):
+    """The snapshot with its global list in another order: groups (array element + members) stay together and move as one,
+    members are permuted inside their group; every tile gets the list."""
+    import random
+    import struct
+    rnd = random.Random(seed)
+    b = bytearray(blob)
+    h = struct.unpack_from("<4I6I7I5I", b, 0)
+    _, E, c = _snapshot_view(blob)
+    items, e = [], c
+    while e != -1:
+        simd, data, nxt, kind = (int(x) for x in E[e])
+        if data != -1:
+            mem, m = [], nxt
+            while True:
+                mem.append(m)
+                if m == data:
+                    break
+                m = int(E[m][2])
+            rnd.shuffle(mem)
+            items.append([e] + mem)
+            e = int(E[data][2])
+        else:
+            items.append([e])
+            e = nxt
+    rnd.shuffle(items)
+    flat = [x for it in items for x in it]
+    for a, nx in zip(flat, flat[1:] + [-1]):
+        struct.pack_into("<i", b, h[14] + 16 * a + 8, nx)
+    for it in items:
+        if len(it) > 1:
+            struct.pack_into("<i", b, h[14] + 16 * it[0] + 4, it[-1])
+    struct.pack_into("<i", b, h[10] + 4 * 38, flat[0])
+    for k in range(h[8]):
+        struct.pack_into("<i", b, h[15] + 4 * k, flat[0])
+    return bytes(b)
+
+
+@pytest.mark.parametrize("name", ["demo01_160", "demo02_160", "demo03_160", "test03_160", "test13_160", "test16_160"])
+def test_the_order_of_the_global_list_decides_no_pixel(qr, oracle, name):
+    """Why qr_hierarchy_apply may keep the previous order where the engine would re-sort by view order (include/qr_hierarchy.h):
+    the list's order decides exact depth ties only.  The reference's own capture with its global list shuffled (two seeds),
+    lists rebuilt from it, renders to the reference's frame pixel for pixel."""
+    blob = load_blob(name)
+    want = load_frame(name) & 0xFFFFFF
+    for seed in (1, 2):
+        frame, _, _ = oracle.render(qr.build_lists(_shuffled_global_list(blob, seed)), threads=4)
+        assert np.array_equal(frame, want), seed
+
+
 def test_numpy_mirrors_have_the_c_layout(qr, tmp_path):
     """quadray-engine_amd.node_dtype / node_state_dtype / node_bounds_dtype against include/qr_hierarchy.h as gcc lays it out."""
     import shutil
