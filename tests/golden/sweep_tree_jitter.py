@@ -9,7 +9,9 @@ renders it.  One line per case: differing pixels against both frames, the number
 pixels differ from the tiling-off frame, also the engine's OWN snapshot of the jittered scene with the camera list in every
 tile and its per-surface lists rebuilt by the same pass -- if that frame equals ours, the difference is the engine's
 bounding-volume arrays in its per-surface lists (they cut members off on these transforms), not the patched hierarchy.
-usage: sweep_tree_jitter.py SEED [SEED ...] > profiles/rNN_hierarchy_jitter_sweep.txt
+usage: sweep_tree_jitter.py [--gpu] SEED [SEED ...] > profiles/rNN_hierarchy_jitter_sweep.txt
+--gpu (on a GPU box; the reference runs on its host cores): the patched snapshot is ALSO uploaded with its tile lists rebuilt by
+the GPU binning pass (QR_UPLOAD_REBIN_TILES) and rendered by the HIP kernel; its frame is compared with the oracle's.
 """
 import json, os, struct, subprocess, sys, tempfile
 import numpy as np
@@ -39,8 +41,9 @@ def run(scene, args, want_snapshot=False):
 
 def main():
     qr = load_package()
-    seeds = sys.argv[1:] or ["1", "2", "3"]
-    n = same = refused = 0
+    gpu = "--gpu" in sys.argv[1:]
+    seeds = [a for a in sys.argv[1:] if a != "--gpu"] or ["1", "2", "3"]
+    n = same = refused = gpu_same = 0
     for scene in SCENES:
         base_name = scene + "_160"
         tb, base = th.load_tree(qr, base_name)
@@ -62,9 +65,17 @@ def main():
                 refused += 1
                 print("%s seed %s: REFUSED %s (transform-node changes %d)" % (scene, seed, e, changed))
                 continue
-            ours, _, _ = qr_oracle.render(qr.build_lists(blob), threads=8)
+            built = qr.build_lists(blob)
+            ours, _, _ = qr_oracle.render(built, threads=8)
             d_t, d_u = int((ours != tiled).sum()), int((ours != untiled).sum())
             note = ""
+            if gpu:
+                sc = qr.Scene(built, rebin_tiles=True)
+                hip = sc.render().cpu().numpy().view(np.uint32) & 0xFFFFFF
+                d_g = int((hip != ours).sum())
+                gpu_same += d_g == 0
+                note = "; HIP kernel with rebinned tiles: %d pixels from the oracle" % d_g
+                del sc
             if d_u:
                 h = struct.unpack_from("<4I6I7I5I", snap, 0)
                 e2 = bytearray(snap)
@@ -72,12 +83,13 @@ def main():
                 for k in range(h[8]):
                     struct.pack_into("<i", e2, h[15] + 4 * k, clist)
                 own, _, _ = qr_oracle.render(qr.build_lists(bytes(e2)), threads=8)
-                note = "; the engine's own snapshot with lists rebuilt: %d pixels from ours" % int((own != ours).sum())
+                note += "; the engine's own snapshot with lists rebuilt: %d pixels from ours" % int((own != ours).sum())
             else:
                 same += 1
             print("%s seed %s: %d pixels from the tiled frame, %d from the tiling-off frame, transform-node changes %d%s"
                   % (scene, seed, d_t, d_u, changed, note))
-    print("# %d cases, %d refused, %d equal to the reference's tiling-off frame pixel for pixel" % (n, refused, same))
+    print("# %d cases, %d refused, %d equal to the reference's tiling-off frame pixel for pixel" % (n, refused, same)
+          + (", HIP kernel equal to the oracle in %d" % gpu_same if gpu else ""))
 
 
 if __name__ == "__main__":
