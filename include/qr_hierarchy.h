@@ -158,6 +158,9 @@ int qr_hierarchy_bounds(const void *blob, uint64_t size, const qr_node *nodes, i
                                  * mappings / scalers may change */
 #define QR_HIER_RESET_TILES 1u  /* qr_hierarchy_apply: point every tile at the global list (the camera may have moved;
                                  * QR_UPLOAD_REBIN_TILES bins again on the GPU) */
+#define QR_HIER_REGROUP     4u  /* qr_hierarchy_apply (with `base`, _RESET_TILES and _BOUNDS): rebuild the global list and every
+                                 * clipper list from their leaves even if no surface changes its transform node -- what a
+                                 * change would trigger by itself; on an unchanged scene the result has the input's structure */
 
 /*
  * Writes the transform fields the nodes' new state implies into a copy of the snapshot: surfaces and array nodes

@@ -178,6 +178,7 @@ def node_state_dtype():
 
 HIER_RESET_TILES = 1
 HIER_BOUNDS = 2
+HIER_REGROUP = 4
 ANIM_SPIN, ANIM_SWING = "spin", "swing"
 
 

@@ -407,6 +407,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
         for (int i = 0; i < n; i++) if (is_surface(next[i].tag) && next[i].srf >= 0) in_table++;
         incomplete = in_list < in_table;
     }
+    if (base != nullptr && (flags & QR_HIER_REGROUP)) regroup = true;
     const bool restructure = regroup || incomplete;
     if (restructure)
     {
@@ -504,7 +505,7 @@ extern "C" int qr_hierarchy_apply(const void *blob, uint64_t size, const qr_node
                 if (el.simd == QR_NULL || el.kind == 2 || v.srf[el.simd].srf_t[3] < 0) continue;
                 const int nd = node_of_rec[(size_t)el.simd];
                 if (nd < 0) return qr_fail(QR_ERR_UNSUP, "a clipper list holds a surface no node of the table owns: cannot regroup it");
-                if (group_before(nd) != group_of(nd)) changes = true;
+                if (group_before(nd) != group_of(nd) || (flags & QR_HIER_REGROUP)) changes = true;
             }
             int32_t nh = h;
             if (changes)

@@ -581,13 +581,59 @@ def test_gpu_any_object_may_start_or_stop_turning(qr, base_name, target_name):
 
 
 def _list_shape(blob, head):
+    """A list as (record, kind, x) per element: x = True for an array element / transform-node marker (`ends` tells where its
+    run ends, as a position in the list), else the element's data word (a clipper's side, an accum marker's sign)."""
     S, E, _ = _snapshot_view(blob)
-    out, e = [], head
+    chain, e = [], head
     while e != -1:
+        chain.append(e)
+        e = int(E[e][2])
+    pos = {e: k for k, e in enumerate(chain)}
+    out = []
+    for e in chain:
         simd, data, nxt, kind = (int(x) for x in E[e])
-        out.append((simd, kind, data != -1 if (kind == 2 or simd >= 0 and int(S[simd].view(np.int32)[37]) == -1) else data))
-        e = nxt
+        if kind == 2 or (simd >= 0 and int(S[simd].view(np.int32)[37]) == -1):
+            out.append((simd, kind, True, pos[data]))
+        else:
+            out.append((simd, kind, data, None))
     return out
+
+
+def _all_tree_cases():
+    out = []
+    for f in sorted(os.listdir(TREE)):
+        if f.endswith(".json.gz"):
+            name = f[:-len(".json.gz")]
+            if name in MANIFEST or os.path.exists(os.path.join(TREE, name + ".qrs.gz")):
+                out.append(name)
+    return out
+
+
+@pytest.mark.parametrize("name", _all_tree_cases())
+def test_regrouping_an_unchanged_scene_gives_the_engines_own_lists(qr, name):
+    """QR_HIER_REGROUP on the engine's capture with its own node table: the global list and EVERY clipper list are rebuilt from
+    their leaves by the code that serves a changing set of transform nodes -- and come out with the ENGINE's structure, element
+    for element: array elements and transform-node markers in front of the same members, accum markers where they were
+    (rt_SceneThread::insert / sclip, engine.cpp:1148-1214, 1845-1947).  Every captured tree: test and demo scenes, jittered,
+    moved, swarms."""
+    t, nodes = load_tree(qr, name)
+    blob = load_blob(name) if name in MANIFEST else _fuzz_blob(name)
+    out = qr.hierarchy_apply(blob, nodes, t["opts"], camera=t["camera"], base=nodes,
+                             flags=qr.HIER_RESET_TILES | qr.HIER_BOUNDS | qr.HIER_REGROUP)
+    S0, E0, c0 = _snapshot_view(blob)
+    S1, E1, c1 = _snapshot_view(out)
+    assert len(S1) == len(S0)                                           # no transform node without a record
+    assert c1 >= len(E0) or c0 == -1                                    # ... and the list IS rebuilt (fresh elements)
+    assert _list_shape(out, c1) == _list_shape(blob, c0)
+    n_lists = 0
+    for r in range(len(S0)):
+        h0, h1 = int(S0[r].view(np.int32)[38]), int(S1[r].view(np.int32)[38])
+        assert (h0 < 0) == (h1 < 0)
+        if h0 >= 0:
+            assert h1 >= len(E0)
+            assert _list_shape(out, h1) == _list_shape(blob, h0), r
+            n_lists += 1
+    assert (S1[:, :38] == S0[:, :38]).all()
 
 
 def test_turning_an_array_and_turning_it_back_restores_the_snapshot(qr, oracle):
@@ -608,7 +654,7 @@ def test_turning_an_array_and_turning_it_back_restores_the_snapshot(qr, oracle):
     turned_after = qr.hierarchy_records_after_apply(original, turned, t2["opts"])
     new = [i for i in range(len(b2)) if turned_after[i]["srf"] != b2[i]["srf"]]
     assert new and all(b2[i]["tag"] == -1 and turned_after[i]["srf"] >= len(S0) for i in new)
-    assert [s for s, k, d in _list_shape(there, c1) if d is True and s >= len(S0)] != []    # ... heads a group of the list
+    assert [x[0] for x in _list_shape(there, c1) if x[2] is True and x[0] >= len(S0)] != []    # ... heads a group of the list
     frame_there, _, _ = oracle.render(qr.build_lists(there), threads=4)
     assert not np.array_equal(frame_there, load_frame("demo02_160") & 0xFFFFFF)
     back_nodes = turned_after.copy()
@@ -652,7 +698,7 @@ def test_surfaces_the_engine_removed_from_its_camera_list_come_back(qr, oracle):
     lame, _, _ = oracle.render(bytes(blob), threads=4)
     assert not np.array_equal(lame, load_frame("test05_160") & 0xFFFFFF)
     patched = qr.hierarchy_apply(bytes(blob), base, t["opts"], camera=t["camera"], base=base, flags=qr.HIER_RESET_TILES | qr.HIER_BOUNDS)
-    assert gone in [s for s, k, d in _list_shape(patched, _snapshot_view(patched)[2])]
+    assert gone in [x[0] for x in _list_shape(patched, _snapshot_view(patched)[2])]
     frame, _, _ = oracle.render(qr.build_lists(patched), threads=4)
     assert np.array_equal(frame, load_frame("test05_160") & 0xFFFFFF)
 
